@@ -1,0 +1,246 @@
+"""CPU oracle for the nViT hot path — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; the product path (nvit_amd/) never does and fails loudly when the
+HIP library is missing.
+
+This is a from-scratch restatement of the reference's algorithm in plain fp32
+PyTorch (CPU), written from the mathematics in SURVEY.md §9.2 as explicit
+matrix products / softmax / norms over a flat {state_dict name -> tensor}
+dictionary.  It is not a transliteration of the reference's nn.Modules: there
+are no modules, no einops, no SDPA and no conv2d calls here.
+
+What each function restates (citations into /root/reference/):
+  nrm            nvit/model.py:43-44      x / ||x||_2, no eps
+  im2col         nvit/model.py:286-304    Conv2d(k=P,s=P_l) (+ReflectionPad2d) as a GEMM operand
+  attend         nvit/model.py:104-127    per-head cosine-normalised attention (SDPA branch :124)
+  lerp           nvit/model.py:134-142    normalised LERP residual
+  cross_block    nvit/model.py:219-275
+  block          nvit/model.py:92-169 + norm_skip :84-87 (called at :452)
+  forward        nvit/model.py:403-470
+  renorm_        nvit/train.py:461-480    post-step weight re-normalisation
+  param_groups   nvit/model.py:369-385    AdamW groups
+  train_step     nvit/train.py:898-946,989-990
+
+Parity status: PINNED.  tests/test_oracle_golden.py checks this file against
+golden vectors produced by importing the real reference on CPU
+(oracle/make_golden.py, run in the build container; fixtures in tests/golden/),
+including the known-answer record of SURVEY.md §9.3.
+
+`lowp` hook: when not None it is applied to every GEMM operand (activations and
+weights) and to the softmax probabilities, emulating "bf16 MFMA operands, fp32
+accumulate" so the bf16 HIP path can be compared at a tight tolerance.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+LowP = Optional[Callable[[Tensor], Tensor]]
+
+
+def bf16_round(t: Tensor) -> Tensor:
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def _lp(t: Tensor, lowp: LowP) -> Tensor:
+    return t if lowp is None else lowp(t)
+
+
+def nrm(x: Tensor) -> Tensor:
+    return x / torch.sqrt((x * x).sum(dim=-1, keepdim=True))
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor], lowp: LowP) -> Tensor:
+    y = _lp(x, lowp) @ _lp(w, lowp).t()
+    return y if b is None else y + b
+
+
+def reflect_index(i: Tensor, n: int) -> Tensor:
+    """ReflectionPad2d index map: -1 -> 1, n -> n-2 (no edge repeat)."""
+    i = torch.where(i < 0, -i, i)
+    return torch.where(i >= n, 2 * (n - 1) - i, i)
+
+
+def im2col(img: Tensor, P: int, stride: int, pad: int) -> Tensor:
+    """[B,ch,S,S] -> [B,T,ch*P*P], column order (c, ph, pw); reflect padding by index map."""
+    B, ch, S, _ = img.shape
+    G = (S + 2 * pad - P) // stride + 1
+    base = torch.arange(G) * stride - pad
+    off = torch.arange(P)
+    rows = reflect_index(base[:, None] + off[None, :], S)          # [G,P]
+    cols = rows
+    # gather: out[b, gy, gx, c, ph, pw] = img[b, c, rows[gy,ph], cols[gx,pw]]
+    x = img[:, :, rows.reshape(-1), :]                              # [B,ch,G*P,S]
+    x = x[:, :, :, cols.reshape(-1)]                                # [B,ch,G*P,G*P]
+    x = x.reshape(B, ch, G, P, G, P).permute(0, 2, 4, 1, 3, 5)      # [B,G,G,ch,P,P]
+    return x.reshape(B, G * G, ch * P * P)
+
+
+def heads(x: Tensor, H: int) -> Tensor:
+    B, T, C = x.shape
+    return x.reshape(B, T, H, C // H).permute(0, 2, 1, 3)           # [B,H,T,d]
+
+
+def attend(q: Tensor, k: Tensor, v: Tensor, s_eff: Tensor, H: int, lowp: LowP) -> Tensor:
+    """softmax(sqrt(d) * qh kh^T) v with qh = s*nrm(q) per head; returns [B,T,C]."""
+    B, T, C = q.shape
+    d = C // H
+    s = s_eff.reshape(1, H, 1, d)
+    qh = s * nrm(heads(q, H))
+    kh = s * nrm(heads(k, H))
+    vh = heads(v, H)
+    scores = (_lp(qh, lowp) @ _lp(kh, lowp).transpose(-1, -2)) * math.sqrt(d)
+    p = torch.softmax(scores, dim=-1)
+    o = _lp(p, lowp) @ _lp(vh, lowp)
+    return o.permute(0, 2, 1, 3).reshape(B, T, C)
+
+
+def lerp(h: Tensor, y: Tensor, alpha: Tensor, c_a: float) -> Tensor:
+    lam = torch.abs(alpha * c_a)
+    a = nrm(h)
+    b = nrm(y)
+    return nrm(a + lam * (b - a))
+
+
+def _b(p: Params, name: str) -> Optional[Tensor]:
+    return p.get(name)
+
+
+def cross_block(p: Params, cfg, local: Tensor, global_: Tensor, lowp: LowP) -> Tensor:
+    pre = "cross_attention."
+    c_q = 1.0 / cfg.base_scale
+    c_a = 0.05 / cfg.base_scale
+    q = linear(local, p[pre + "q_local.weight"], _b(p, pre + "q_local.bias"), lowp)
+    k = linear(global_, p[pre + "k_global.weight"], _b(p, pre + "k_global.bias"), lowp)
+    v = linear(global_, p[pre + "v_global.weight"], _b(p, pre + "v_global.bias"), lowp)
+    o = attend(q, k, v, p[pre + "sqk"] * c_q, cfg.n_head, lowp)
+    o = linear(o, p[pre + "proj.weight"], _b(p, pre + "proj.bias"), lowp)
+    C = cfg.n_embd
+    u, g = o[..., :C], o[..., C:]
+    o = u * (g * torch.sigmoid(g))
+    o = linear(o, p[pre + "out_proj.weight"], _b(p, pre + "out_proj.bias"), lowp)
+    return lerp(local, o, p[pre + "attn_alpha"], c_a)
+
+
+def block(p: Params, cfg, i: int, x: Tensor, lowp: LowP) -> Tensor:
+    pre = f"transformer.h.{i}."
+    C = cfg.n_embd
+    c_q = 1.0 / cfg.base_scale
+    c_a = 0.05 / cfg.base_scale
+    q = linear(x, p[pre + "query.weight"], _b(p, pre + "query.bias"), lowp)
+    k = linear(x, p[pre + "key.weight"], _b(p, pre + "key.bias"), lowp)
+    v = linear(x, p[pre + "value.weight"], _b(p, pre + "value.bias"), lowp)
+    o = attend(q, k, v, p[pre + "sqk"] * c_q, cfg.n_head, lowp)
+    y = linear(o, p[pre + "att_c_proj.weight"], _b(p, pre + "att_c_proj.bias"), lowp)
+    h1 = lerp(x, y, p[pre + "attn_alpha"], c_a)
+    uv = linear(h1, p[pre + "c_fc.weight"], _b(p, pre + "c_fc.bias"), lowp)
+    uv = uv * (p[pre + "suv"] * (1.0 * math.sqrt(C)))
+    u, g = uv[..., : 4 * C], uv[..., 4 * C:]
+    xm = u * (g * torch.sigmoid(g))
+    y2 = linear(xm, p[pre + "mlp_c_proj.weight"], _b(p, pre + "mlp_c_proj.bias"), lowp)
+    h2 = lerp(h1, y2, p[pre + "mlp_alpha"], c_a)
+    return nrm(h2 * p[pre + "skip_param"] + x)
+
+
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def embed(p: Params, cfg, img: Tensor, lowp: LowP) -> Tuple[Tensor, Tensor, Tensor]:
+    Pl, Pg = cfg.local_patch_size, cfg.global_patch_size
+    C = cfg.n_embd
+    A_l = im2col(img, Pl, Pl, 0)
+    A_g = im2col(img, Pg, Pl, (Pg - Pl) // 2)
+    loc = linear(A_l, p["local_patch_embed.weight"].reshape(C, -1), p["local_patch_embed.bias"], lowp)
+    glo = linear(A_g, p["global_patch_embed.1.weight"].reshape(C, -1), p["global_patch_embed.1.bias"], lowp)
+    return loc + p["local_pos_embed"], glo + p["global_pos_embed"], A_l
+
+
+def forward(p: Params, cfg, img: Tensor, lowp: LowP = None, taps: Optional[dict] = None):
+    """-> (logits [B,ncls], {"reconstruction": scalar}); non-Kohonen branch (model.py:445-447)."""
+    assert cfg.use_nvit and not cfg.use_kohonen
+    loc, glo, A_l = embed(p, cfg, img, lowp)
+    x = cross_block(p, cfg, loc, glo, lowp)
+    if taps is not None:
+        taps["loc"], taps["glo"], taps["x0"] = loc, glo, x
+    for i in range(cfg.n_layer):
+        x = block(p, cfg, i, x, lowp)
+        if taps is not None:
+            taps[f"x{i + 1}"] = x
+    pooled = x.mean(dim=1)
+    ln = layer_norm(pooled, p["mlp_head.0.weight"], p["mlp_head.0.bias"])
+    logits = linear(ln, p["mlp_head.1.weight"], p["mlp_head.1.bias"], lowp)
+    logits = logits * (p["sz"] * (cfg.sz_init_value / cfg.sz_init_scaling))
+    rec = torch.tanh(linear(x, p["reconstruction_head.0.weight"], p["reconstruction_head.0.bias"], lowp))
+    recon = ((rec - A_l) ** 2).mean()
+    return logits, {"reconstruction": recon}
+
+
+def cross_entropy(logits: Tensor, y: Tensor) -> Tensor:
+    lse = torch.logsumexp(logits, dim=-1)
+    return (lse - logits.gather(1, y[:, None]).squeeze(1)).mean()
+
+
+RENORM_ROWS = ("query", "key", "value", "c_fc")          # dim=1 (train.py:475-477,479)
+RENORM_COLS = ("att_c_proj", "mlp_c_proj")               # dim=0 (train.py:478,480)
+
+
+@torch.no_grad()
+def renorm_(p: Params, cfg) -> None:
+    for i in range(cfg.n_layer):
+        for n in RENORM_ROWS:
+            w = p[f"transformer.h.{i}.{n}.weight"]
+            w.copy_(w / torch.sqrt((w * w).sum(dim=1, keepdim=True)))
+        for n in RENORM_COLS:
+            w = p[f"transformer.h.{i}.{n}.weight"]
+            w.copy_(w / torch.sqrt((w * w).sum(dim=0, keepdim=True)))
+
+
+def param_groups(p: Params, weight_decay: float):
+    """model.py:369-385 nViT branch: decay >=2-D non-'sz' params; no decay for <2-D and sz."""
+    decay = [t for n, t in p.items() if "sz" not in n and t.dim() >= 2]
+    nodecay = [t for n, t in p.items() if "sz" not in n and t.dim() < 2]
+    return [
+        {"params": decay, "weight_decay": weight_decay},
+        {"params": nodecay, "weight_decay": 0.0},
+        {"params": [p["sz"]], "weight_decay": 0.0},
+    ]
+
+
+def make_params(state: Dict[str, Tensor]) -> Params:
+    return {n: t.detach().clone().float().requires_grad_(True) for n, t in state.items()}
+
+
+def make_optimizer(p: Params, lr: float = 1e-3, weight_decay: float = 0.1, betas=(0.9, 0.95)):
+    return torch.optim.AdamW(param_groups(p, weight_decay), lr=lr, betas=betas)
+
+
+def loss_and_grads(p: Params, cfg, X: Tensor, y: Tensor, lowp: LowP = None):
+    for t in p.values():
+        t.grad = None
+    logits, aux = forward(p, cfg, X, lowp)
+    loss = cross_entropy(logits, y)
+    loss.backward()
+    return logits.detach(), loss.detach(), aux["reconstruction"].detach()
+
+
+def total_grad_norm(p: Params) -> Tensor:
+    gs = [t.grad for t in p.values() if t.grad is not None]
+    return torch.sqrt(sum((g * g).sum() for g in gs))
+
+
+def train_step(p: Params, cfg, opt, X: Tensor, y: Tensor, grad_clip: float = 1.0, lowp: LowP = None):
+    """forward -> CE -> backward -> clip -> AdamW -> zero_grad -> renorm (train.py:898-946,989-990)."""
+    logits, loss, recon = loss_and_grads(p, cfg, X, y, lowp)
+    gnorm = torch.nn.utils.clip_grad_norm_([t for t in p.values() if t.grad is not None], grad_clip)
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    renorm_(p, cfg)
+    return logits, loss, recon, gnorm

@@ -1,0 +1,87 @@
+"""Pins oracle/nvit_oracle.py against golden vectors produced by the real reference
+(oracle/make_golden.py; reference: /root/reference/nvit/model.py, train.py:461-480,898-946).
+
+CPU only. Tolerances: fp32 accumulation-order noise between the reference's
+conv2d/SDPA/einops formulation and the oracle's explicit-GEMM formulation."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from nvit_amd.config import named_config
+from nvit_amd.weights import formula_state_dict, synthetic_batch
+from oracle import nvit_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+FILES = sorted(glob.glob(os.path.join(GOLD, "*_b*_*.npz")))
+
+
+def _case(path):
+    base = os.path.basename(path)[:-4]
+    name, b, state = base.rsplit("_", 2)
+    return name, int(b[1:]), state == "renorm"
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f)[:-4] for f in FILES])
+def test_oracle_matches_reference_golden(path):
+    torch.set_num_threads(4)
+    name, batch, renormed = _case(path)
+    g = np.load(path)
+    cfg = named_config(name)
+    p = O.make_params(formula_state_dict(cfg, perturb_scalars=True))
+    if renormed:
+        O.renorm_(p, cfg)
+    X, y = synthetic_batch(cfg, batch)
+    opt = O.make_optimizer(p)
+    # forward / backward
+    logits, loss, recon = O.loss_and_grads(p, cfg, X, y)
+    assert np.abs(logits.numpy() - g["logits"]).max() < 2e-5
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    assert abs(recon.item() - float(g["recon"])) < 2e-5
+    names = [str(n) for n in g["grad_names"]]
+    got = {n for n, t in p.items() if t.grad is not None}
+    assert got == set(names), "set of parameters receiving gradients differs (SURVEY §9.1-Q6)"
+    for n, gn, gh in zip(names, g["grad_norms"], g["grad_heads"]):
+        grad = p[n].grad
+        mine = grad.double().norm().item()
+        assert abs(mine - gn) <= 2e-4 * gn + 1e-7, (n, mine, gn)
+        head = grad.reshape(-1)[:8].numpy() if grad.numel() >= 8 else np.resize(grad.reshape(-1).numpy(), 8)
+        assert np.abs(head - gh).max() <= 2e-4 * max(np.abs(gh).max(), 1e-30) + 2e-7, n
+    # clip -> AdamW -> renorm, then step-1 forward
+    gnorm = torch.nn.utils.clip_grad_norm_([t for t in p.values() if t.grad is not None], 1.0)
+    assert abs(gnorm.item() - float(g["gnorm"])) < 2e-4 * float(g["gnorm"])
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    O.renorm_(p, cfg)
+    with torch.no_grad():
+        logits1, aux1 = O.forward(p, cfg, X)
+        loss1 = O.cross_entropy(logits1, y)
+    assert np.abs(logits1.numpy() - g["logits1"]).max() < 5e-5
+    assert abs(loss1.item() - float(g["loss1"])) < 5e-5
+    assert abs(aux1["reconstruction"].item() - float(g["recon1"])) < 5e-5
+    q0 = p["transformer.h.0.query.weight"].detach().reshape(-1)[:8].numpy()
+    assert np.abs(q0 - g["q0_head1"]).max() < 1e-6
+    pl = p[f"transformer.h.{cfg.n_layer - 1}.mlp_c_proj.weight"].detach().reshape(-1)[:8].numpy()
+    assert np.abs(pl - g["p_last_head1"]).max() < 1e-6
+    # weight norms after renorm: rows (dim=1) / columns (dim=0) are unit
+    for i in range(cfg.n_layer):
+        for n in O.RENORM_ROWS:
+            w = p[f"transformer.h.{i}.{n}.weight"].detach()
+            assert (w.norm(dim=1) - 1).abs().max() < 1e-6
+        for n in O.RENORM_COLS:
+            w = p[f"transformer.h.{i}.{n}.weight"].detach()
+            assert (w.norm(dim=0) - 1).abs().max() < 1e-6
+
+
+def test_im2col_reflect_matches_torch_ops():
+    """oracle.im2col vs torch's own ReflectionPad2d+unfold (operator semantics of model.py:295-304)."""
+    img = torch.randn(2, 3, 24, 24, generator=torch.Generator().manual_seed(3))
+    mine = O.im2col(img, 16, 8, 4)
+    pad = torch.nn.functional.pad(img, (4, 4, 4, 4), mode="reflect")
+    ref = torch.nn.functional.unfold(pad, kernel_size=16, stride=8).transpose(1, 2)
+    assert torch.equal(mine, ref)
+    mine_l = O.im2col(img, 8, 8, 0)
+    ref_l = torch.nn.functional.unfold(img, kernel_size=8, stride=8).transpose(1, 2)
+    assert torch.equal(mine_l, ref_l)
