@@ -1,0 +1,182 @@
+/* nvit_hip.h — C ABI of the MI355X (gfx950) nViT hot-path library (libnvit_hip.so).
+ *
+ * Drop-in boundary: the reference has no FFI; its seams are the Python
+ * classes in /root/reference/nvit/model.py and Trainer.normalize_matrices
+ * (/root/reference/nvit/train.py:461-480).  Every entry point below replaces the torch
+ * operator sequence cited next to it.  Conventions:
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless marked host;
+ *   - the caller owns every buffer (outputs, workspaces, saved-for-backward tensors);
+ *     the library never allocates, frees or keeps a pointer past the call;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); calls are
+ *     asynchronous and re-entrant (forward on the main thread, backward on the autograd
+ *     thread); the only global state is the optional event-timing table (nvit_prof_*);
+ *   - return 0 on success, NVIT_EINVAL for a rejected argument, else a hipError_t value;
+ *     nvit_last_error() gives the calling thread's message.  No exception crosses the ABI.
+ *   - `dt` selects the activation / MFMA-operand type: NVIT_F32 (exact-f32 MFMA path,
+ *     parity <=1e-5) or NVIT_BF16 (bf16 operands, fp32 accumulate).  The residual stream,
+ *     parameters, gradients and all reductions are fp32 in both modes.
+ *   - token-major activations are [M, C] with M = B*T rows; per-head tensors are
+ *     [B, H, T, d] contiguous.
+ */
+#ifndef NVIT_HIP_H
+#define NVIT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVIT_OK 0
+#define NVIT_EINVAL 1001
+#define NVIT_F32 0
+#define NVIT_BF16 1
+
+int nvit_version(void);
+const char* nvit_last_error(void);
+
+/* ---- event timing of kernel families (bench.py roofline leg) ------------------ */
+#define NVIT_KID_GEMM_NT 0
+#define NVIT_KID_GEMM_TN 1
+#define NVIT_KID_ATTN_FWD 2
+#define NVIT_KID_ATTN_BWD 3
+#define NVIT_KID_ROWOPS 4
+#define NVIT_KID_RENORM 5
+#define NVIT_KID_SHADOW 6
+#define NVIT_KID_PATCHIFY 7
+#define NVIT_KID_MISC 8
+#define NVIT_KID_COUNT 9
+void nvit_prof_enable(int on);
+/* Synchronises the recorded events and returns, per kernel family, total milliseconds,
+ * algorithmic FLOPs, algorithmic bytes and launch count since the last collect. Host arrays
+ * of NVIT_KID_COUNT entries. */
+int nvit_prof_collect(double* ms, double* flops, double* bytes, int64_t* launches);
+const char* nvit_prof_name(int kid);
+
+/* ---- weights --------------------------------------------------------------------
+ * nvit_renorm_weights: Trainer.normalize_matrices (train.py:461-480) as ONE persistent
+ * launch.  `table` is a device array of n rows of 5 int64: {ptr, rows, cols, dim, first_item}
+ * dim=1: every row scaled to unit L2 norm (query/key/value/c_fc); dim=0: every column
+ * (att_c_proj/mlp_c_proj).  fp32 in place, one read + one write per element.
+ * first_item = prefix sum of work items (rows/NVIT_RENORM_ROWS_PER_ITEM for dim=1,
+ * cols/NVIT_RENORM_COLS_PER_ITEM for dim=0, rounded up); total_items = sum.
+ * dim=0 needs rows*NVIT_RENORM_COLS_PER_ITEM*4 bytes <= 144 KiB of LDS (rows <= 1152). */
+#define NVIT_RENORM_ROWS_PER_ITEM 16
+#define NVIT_RENORM_COLS_PER_ITEM 32
+int nvit_renorm_weights(const int64_t* table, int n, int total_items, void* stream);
+
+/* nvit_shadow_weights: builds the private MFMA-operand copies of the fp32 master weights
+ * (SURVEY.md §8b "state_dict contract": non-persistent shadows) in ONE launch.  `table` =
+ * device array of n rows of 12 int64:
+ *   {src, rows, cols, dst, dst_ld, dst_cols, dstT, dstT_ld, dstT_cols, perm, first_item, tiles_c}
+ *   dst  [rows, dst_ld]  : dst[r, c] = src[perm(r), c] for c < cols, 0 for cols <= c < dst_cols
+ *   dstT [cols, dstT_ld] : dstT[c, r] = dst[r, c] for r < rows, 0 for rows <= r < dstT_cols
+ *   Either dst or dstT may be 0 (skipped).  dst/dstT may point inside a larger concatenated
+ *   buffer (Q|K|V stacking); only the stated extents are written.
+ *   perm: 0 identity; 1 = SwiGLU interleave of a [2F, K] matrix: shadow row 32q+w is
+ *         source row 16q+w (w<16, "u") or F+16q+(w-16) (w>=16, "v").
+ *   Work items are 64x64 tiles: tiles_c = ceil(max(cols,dst_cols)/64) tile columns,
+ *   ceil(max(rows,dstT_cols)/64) tile rows; first_item = prefix sum; total_items = sum.
+ * Element type of dst/dstT is `dt`. */
+int nvit_shadow_weights(const int64_t* table, int n, int total_items, int dt, void* stream);
+
+/* ---- GEMMs ------------------------------------------------------------------------
+ * nvit_gemm_nt: C[M,N] = A[M,K] * B[N,K]^T  (nn.Linear: model.py:99-101,130,148,155,...)
+ * A, B of type dt, K % (128/sizeof(dt)) == 0, lda/ldb multiples of 16 bytes.
+ * Epilogue, in this order: +bias[n]; *colscale[n]; +rowadd[(m % rowadd_period)*N + n];
+ * + old C (accumulate!=0); store as out_dt (NVIT_F32 / NVIT_BF16) with leading dim ldc. */
+int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int out_dt,
+                 int M, int N, int K, const float* bias, const float* colscale, const float* rowadd,
+                 int rowadd_period, int accumulate, void* stream);
+
+/* nvit_gemm_tn: weight gradient  G[N,K] (+)= sum_m A[m,N-col] * B[m,K-col]  over Mred rows.
+ * A [Mred, N] (lda), B [Mred, K] (ldb) of type dt.  Split over `splits` row chunks into the
+ * fp32 workspace ws [splits, N, K] (ws_bytes >= splits*N*K*4), then reduced in fixed order
+ * (deterministic) into G (fp32, ld = ldg): G[perm(n)] = (accumulate ? G : 0) + sum.
+ * perm as in nvit_shadow_weights (maps shadow row n to master row). */
+int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int ldb, float* G, int ldg, int Mred, int N,
+                 int K, int splits, float* ws, int64_t ws_bytes, int perm, int accumulate, void* stream);
+
+/* ---- row-wise fused ops on the fp32 residual stream --------------------------------
+ * nvit_lerp_fwd: out = nrm(nrm(h) + |alpha*c_a| * (nrm(y) - nrm(h)))   (model.py:134-142,159-167)
+ * if skip_x != NULL additionally out = nrm(out*skip[0] + skip_x)         (norm_skip, model.py:84-87,452)
+ * h, skip_x fp32 [M,C]; y of type y_dt; out fp32; out_lo (type dt, may be NULL) = cast(out). */
+int nvit_lerp_fwd(int dt, const float* h, const void* y, int y_dt, const float* alpha, float c_a,
+                  const float* skip_x, const float* skip, float* out, void* out_lo, int M, int C, void* stream);
+/* nvit_lerp_bwd: given dout, recomputes the forward and writes dh (fp32; += if accum_dh), dy (fp32
+ * and/or type-dt copy, either may be NULL), dskip_x (fp32, written, only if skip_x), and per-block
+ * partial sums part_dlam [nblk, C] (d/d|alpha*c_a|) and part_dskip [nblk] (if skip_x).
+ * nblk = number of workgroups the caller sizes the partial buffers for (<= 4096). */
+int nvit_lerp_bwd(int dt, const float* dout, const float* h, const void* y, int y_dt, const float* alpha,
+                  float c_a, const float* skip_x, const float* skip, float* dh, int accum_dh, float* dy,
+                  void* dy_lo, float* dskip_x, float* part_dlam, float* part_dskip, int nblk, int M, int C,
+                  void* stream);
+
+/* nvit_qknorm_fwd: per-head cosine normalise + learned scale + head split (model.py:104-119,231-247)
+ * q/k/v sources: row-major, type dt, row stride ld* elements, C columns each.
+ * qh = (sqk*c_q) * nrm_d(q) etc. written [B,H,T,d] type dt; v copied to [B,H,T,d];
+ * rq, rk [M,H] fp32 = 1/||q_head||. */
+int nvit_qknorm_fwd(int dt, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                    const float* sqk, float c_q, void* qh, void* kh, void* vh, float* rq, float* rk, int B,
+                    int T, int H, int d, void* stream);
+/* nvit_qknorm_bwd: dq/dk/dv (type dt, row strides ld*) from dqh/dkh/dvh [B,H,T,d]; part_dsqk
+ * [nblk, C] partial sums of d/d(sqk*c_q). */
+int nvit_qknorm_bwd(int dt, const void* dqh, const void* dkh, const void* dvh, const void* qh, const void* kh,
+                    const float* rq, const float* rk, const float* sqk, float c_q, void* dq, int ldq,
+                    void* dk, int ldk, void* dv, int ldv, float* part_dsqk, int nblk, int B, int T, int H,
+                    int d, void* stream);
+
+/* nvit_swiglu_fwd: x[m,j] = (gu*u) * silu(gv*v), u = uv[m, 32*(j/16) + j%16], v = uv[m, 32*(j/16)+16+j%16]
+ * (interleaved GEMM output, see perm=1), gu = gscale*suv[j], gv = gscale*suv[F+j]; suv may be NULL (=1)
+ * (model.py:148-154 with gscale = sqrt(C); cross-attention gate model.py:259-261 with suv=NULL). */
+int nvit_swiglu_fwd(int dt, const void* uv, const float* suv, float gscale, void* x, int M, int F, void* stream);
+/* nvit_swiglu_bwd: duv (interleaved, type dt) and part_dsuv [nblk_rows, 2F] (natural order, d/d(suv),
+ * already multiplied by gscale; skipped if suv NULL). rows_per_blk rows per partial. */
+int nvit_swiglu_bwd(int dt, const void* dx, const void* uv, const float* suv, float gscale, void* duv,
+                    float* part_dsuv, int rows_per_blk, int M, int F, void* stream);
+
+/* nvit_colsum_reduce: out[n] (+)= f(sum_b part[b, n]).  kind 0: plain*scale; kind 1: sum * sign(ref[n]*scale) * scale
+ * (d|alpha c_a| -> d alpha); kind 2: plain*scale written to out[perm1(n)] (SwiGLU interleave -> natural order). */
+int nvit_colsum_reduce(const float* part, int nblk, int N, float* out, int accumulate, int kind, const float* ref,
+                       float scale, void* stream);
+/* nvit_colsum: out[n] (+)= scale * sum_r a[r,n] * (b ? b[r,n] : 1) over R rows; a,b fp32 or dt (a_dt,b_dt);
+ * `period`>0 folds rows modulo period: out[(r%period), n] (pos-embed gradients). */
+int nvit_colsum(const void* a, int a_dt, int lda, const void* b, int b_dt, int ldb, int R, int N, int period,
+                float* out, int accumulate, float scale, void* stream);
+int nvit_cast(const float* src, void* dst, int dt, int64_t n, void* stream);
+/* out[r,n] = a[r,n] * s[n] * c   (sz scaling model.py:466-468 and its backward) */
+int nvit_scale_cols(const float* a, int lda, const float* s, float c, void* out, int out_dt, int ldo, int R, int N,
+                    void* stream);
+
+/* ---- attention ------------------------------------------------------------------------
+ * O = softmax(scale * qh kh^T) vh per (b,h), non-causal, no mask (model.py:121-124 SDPA branch).
+ * qh,kh,vh [B,H,T,d] type dt; o [B,T,H*d] type dt (heads merged, model.py:127); lse [B,H,T] fp32
+ * (natural log of the softmax denominator, including the running max).  d in {32,64}.
+ * impl: 0 = scalar-FMA reference kernel (any dt), 1 = MFMA flash kernel (bf16 only). */
+int nvit_attn_fwd(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, void* o, float* lse,
+                  int B, int H, int Tq, int Tk, int d, void* stream);
+/* delta [B,H,T] workspace fp32. dqh,dkh,dvh [B,H,T,d] type dt. */
+int nvit_attn_bwd(int dt, int impl, const void* dout, const void* qh, const void* kh, const void* vh, const void* o,
+                  const float* lse, float scale, void* dqh, void* dkh, void* dvh, float* delta, int B, int H,
+                  int Tq, int Tk, int d, void* stream);
+
+/* ---- patch embedding / head / reconstruction -------------------------------------------
+ * nvit_im2col: A_l [M, ch*Pl*Pl] and A_g [M, ch*Pg*Pg] (type dt, column order (c,ph,pw)) from
+ * img fp32 [B,ch,S,S]; global windows are reflect-padded by (Pg-Pl)/2 and strided by Pl
+ * (model.py:286-304,407-408). */
+int nvit_im2col(int dt, const float* img, void* A_l, void* A_g, int B, int ch, int S, int Pl, int Pg, void* stream);
+/* mean over tokens + LayerNorm(eps) (model.py:455-456, mlp_head.0): x fp32 [B,T,C] ->
+ * pooled [B,C] fp32, ln [B,C] fp32 and ln_lo (type dt, ld = C), stats [B,2] = {mean, rstd}. ws [B, nchunk, C]. */
+int nvit_pool_ln_fwd(int dt, const float* x, const float* w, const float* b, float eps, float* pooled, float* ln,
+                     void* ln_lo, float* stats, float* ws, int nchunk, int B, int T, int C, void* stream);
+/* backward of the above: dln [B,C] fp32 -> dx [B,T,C] fp32 (written, broadcast /T), dw, db (+=). */
+int nvit_pool_ln_bwd(const float* dln, const float* pooled, const float* w, const float* stats, float* dx,
+                     float* dw, float* db, int accumulate, int B, int T, int C, void* stream);
+/* recon loss (model.py:459-464): raw fp32 [M, ch*P*P] = x W_r^T + b_r; loss = mean((tanh(raw) - patch(img))^2).
+ * part [nblk] partial sums; loss[0] written by a fixed-order final reduce. */
+int nvit_recon_loss(const float* raw, const float* img, float* part, int nblk, float* loss, int B, int ch, int S,
+                    int P, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVIT_HIP_H */

@@ -1,0 +1,76 @@
+"""ctypes binding of libnvit_hip.so (the C ABI declared in include/nvit_hip.h).
+
+The product path has NO CPU or PyTorch fallback: if the library is missing or a call
+fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnvit_hip.so")
+
+F32, BF16 = 0, 1
+KID_NAMES = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "rowops", "renorm", "shadow", "patchify", "misc"]
+RENORM_ROWS_PER_ITEM = 16
+RENORM_COLS_PER_ITEM = 32
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> argtypes (restype is int unless listed in _RESTYPES)
+SIGNATURES = {
+    "nvit_version": [],
+    "nvit_last_error": [],
+    "nvit_prof_enable": [_i],
+    "nvit_prof_collect": [_vp, _vp, _vp, _vp],
+    "nvit_prof_name": [_i],
+    "nvit_renorm_weights": [_vp, _i, _i, _vp],
+    "nvit_shadow_weights": [_vp, _i, _i, _i, _vp],
+    "nvit_gemm_nt": [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "nvit_gemm_tn": [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i64, _i, _i, _vp],
+    "nvit_lerp_fwd": [_i, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "nvit_lerp_bwd": [_i, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "nvit_qknorm_fwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "nvit_qknorm_bwd": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i,
+                        _i, _i, _vp],
+    "nvit_swiglu_fwd": [_i, _vp, _vp, _f, _vp, _i, _i, _vp],
+    "nvit_swiglu_bwd": [_i, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
+    "nvit_colsum_reduce": [_vp, _i, _i, _vp, _i, _i, _vp, _f, _vp],
+    "nvit_colsum": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _f, _vp],
+    "nvit_cast": [_vp, _vp, _i, _i64, _vp],
+    "nvit_scale_cols": [_vp, _i, _vp, _f, _vp, _i, _i, _i, _i, _vp],
+    "nvit_attn_fwd": [_i, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "nvit_attn_bwd": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "nvit_im2col": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "nvit_pool_ln_fwd": [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "nvit_pool_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "nvit_recon_loss": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+}
+_RESTYPES = {"nvit_last_error": C.c_char_p, "nvit_prof_name": C.c_char_p, "nvit_prof_enable": None}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise loudly when it is absent (no fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"nvit_amd: {LIB_PATH} not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the nViT hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, C.c_int)
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().nvit_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

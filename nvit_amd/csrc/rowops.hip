@@ -1,0 +1,628 @@
+// Row-wise fp32 kernels on the residual stream: normalised LERP (+norm_skip) forward/backward,
+// per-head cosine normalisation forward/backward, SwiGLU gate forward/backward, and the small
+// column reductions that turn per-block partial sums into parameter gradients.
+// HBM-bound: one wave owns one row (16-byte loads, all reductions by lane shuffles), rows are
+// grid-strided, per-column partial sums stay in registers until the wave's last row.
+#include "common.h"
+
+namespace {
+
+constexpr int ROW_WAVES = 4;  // waves (rows in flight) per 256-thread workgroup
+
+// Each lane owns NV float4 groups of a row: columns (i*64 + lane)*4 .. +3, i < NV, while < C.
+template <int NV>
+struct RowVec {
+  f32x4 v[NV];
+};
+
+template <int NV, typename T>
+__device__ __forceinline__ void row_load(RowVec<NV>& r, const T* p, int C, int lane) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    r.v[i] = c < C ? load4<T>(p + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+template <int NV, typename T>
+__device__ __forceinline__ void row_store(const RowVec<NV>& r, T* p, int C, int lane) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) store4<T>(p + c, r.v[i]);
+  }
+}
+template <int NV>
+__device__ __forceinline__ float row_dot(const RowVec<NV>& a, const RowVec<NV>& b) {
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += a.v[i][0] * b.v[i][0] + a.v[i][1] * b.v[i][1] + a.v[i][2] * b.v[i][2] + a.v[i][3] * b.v[i][3];
+  return wave_sum(s);
+}
+
+// ------------------------------------------------------------------------------ LERP forward
+struct LerpFwdArgs {
+  const float* h;
+  const void* y;
+  const float* alpha;
+  float c_a;
+  const float* skip_x;
+  const float* skip;
+  float* out;
+  void* out_lo;
+  int M, C;
+};
+
+template <int NV, typename TY, typename TL>
+__global__ __launch_bounds__(256) void lerp_fwd_kernel(LerpFwdArgs a) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  RowVec<NV> lam;
+  row_load<NV, float>(lam, a.alpha, a.C, lane);
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lam.v[i][e] = fabsf(lam.v[i][e] * a.c_a);
+  const float skip = a.skip_x ? a.skip[0] : 0.f;
+  for (int m = blockIdx.x * ROW_WAVES + wid; m < a.M; m += gridDim.x * ROW_WAVES) {
+    RowVec<NV> x, y, r;
+    row_load<NV, float>(x, a.h + (size_t)m * a.C, a.C, lane);
+    row_load<NV, TY>(y, reinterpret_cast<const TY*>(a.y) + (size_t)m * a.C, a.C, lane);
+    const float rsx = 1.0f / sqrtf(row_dot<NV>(x, x));
+    const float rsy = 1.0f / sqrtf(row_dot<NV>(y, y));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const f32x4 av = x.v[i] * rsx, bv = y.v[i] * rsy;
+      r.v[i] = av + lam.v[i] * (bv - av);
+    }
+    const float rsr = 1.0f / sqrtf(row_dot<NV>(r, r));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) r.v[i] = r.v[i] * rsr;
+    if (a.skip_x) {
+      RowVec<NV> xs;
+      row_load<NV, float>(xs, a.skip_x + (size_t)m * a.C, a.C, lane);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) r.v[i] = r.v[i] * skip + xs.v[i];
+      const float rst = 1.0f / sqrtf(row_dot<NV>(r, r));
+#pragma unroll
+      for (int i = 0; i < NV; ++i) r.v[i] = r.v[i] * rst;
+    }
+    row_store<NV, float>(r, a.out + (size_t)m * a.C, a.C, lane);
+    if (a.out_lo) row_store<NV, TL>(r, reinterpret_cast<TL*>(a.out_lo) + (size_t)m * a.C, a.C, lane);
+  }
+}
+
+// ------------------------------------------------------------------------------ LERP backward
+struct LerpBwdArgs {
+  const float* dout;
+  const float* h;
+  const void* y;
+  const float* alpha;
+  float c_a;
+  const float* skip_x;
+  const float* skip;
+  float* dh;
+  int accum_dh;
+  float* dy;
+  void* dy_lo;
+  float* dskip_x;
+  float* part_dlam;
+  float* part_dskip;
+  int M, C;
+};
+
+template <int NV, typename TY, typename TL>
+__global__ __launch_bounds__(256) void lerp_bwd_kernel(LerpBwdArgs a) {
+  __shared__ float red[ROW_WAVES][NV * 256 + 4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  RowVec<NV> lam, dlam;
+  row_load<NV, float>(lam, a.alpha, a.C, lane);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    dlam.v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) lam.v[i][e] = fabsf(lam.v[i][e] * a.c_a);
+  }
+  const float skip = a.skip_x ? a.skip[0] : 0.f;
+  float dskip_acc = 0.f;
+  for (int m = blockIdx.x * ROW_WAVES + wid; m < a.M; m += gridDim.x * ROW_WAVES) {
+    RowVec<NV> x, y, av, bv, o, g;
+    row_load<NV, float>(x, a.h + (size_t)m * a.C, a.C, lane);
+    row_load<NV, TY>(y, reinterpret_cast<const TY*>(a.y) + (size_t)m * a.C, a.C, lane);
+    row_load<NV, float>(g, a.dout + (size_t)m * a.C, a.C, lane);
+    const float rsx = 1.0f / sqrtf(row_dot<NV>(x, x));
+    const float rsy = 1.0f / sqrtf(row_dot<NV>(y, y));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      av.v[i] = x.v[i] * rsx;
+      bv.v[i] = y.v[i] * rsy;
+      o.v[i] = av.v[i] + lam.v[i] * (bv.v[i] - av.v[i]);
+    }
+    const float rsr = 1.0f / sqrtf(row_dot<NV>(o, o));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o.v[i] = o.v[i] * rsr;  // o = h2 = lerp output (unit norm)
+    if (a.skip_x) {
+      // t = o*skip + xs ; out = t/|t| ; dt = (g - out<out,g>)/|t| ; do = skip*dt ; dxs = dt ; dskip += <dt,o>
+      RowVec<NV> t;
+      row_load<NV, float>(t, a.skip_x + (size_t)m * a.C, a.C, lane);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) t.v[i] = o.v[i] * skip + t.v[i];
+      const float rst = 1.0f / sqrtf(row_dot<NV>(t, t));
+#pragma unroll
+      for (int i = 0; i < NV; ++i) t.v[i] = t.v[i] * rst;
+      const float tg = row_dot<NV>(t, g);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) g.v[i] = (g.v[i] - t.v[i] * tg) * rst;  // g = dt
+      row_store<NV, float>(g, a.dskip_x + (size_t)m * a.C, a.C, lane);
+      dskip_acc += row_dot<NV>(g, o);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) g.v[i] = g.v[i] * skip;  // g = d(lerp output)
+    }
+    // dr = (g - o<o,g>) * rsr
+    const float og = row_dot<NV>(o, g);
+    RowVec<NV> da, db;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const f32x4 dr = (g.v[i] - o.v[i] * og) * rsr;
+      dlam.v[i] += dr * (bv.v[i] - av.v[i]);
+      da.v[i] = dr - lam.v[i] * dr;
+      db.v[i] = lam.v[i] * dr;
+    }
+    const float ada = row_dot<NV>(av, da);
+    const float bdb = row_dot<NV>(bv, db);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      da.v[i] = (da.v[i] - av.v[i] * ada) * rsx;  // dh
+      db.v[i] = (db.v[i] - bv.v[i] * bdb) * rsy;  // dy
+    }
+    float* dhp = a.dh + (size_t)m * a.C;
+    if (a.accum_dh) {
+      RowVec<NV> old;
+      row_load<NV, float>(old, dhp, a.C, lane);
+#pragma unroll
+      for (int i = 0; i < NV; ++i) da.v[i] += old.v[i];
+    }
+    row_store<NV, float>(da, dhp, a.C, lane);
+    if (a.dy) row_store<NV, float>(db, a.dy + (size_t)m * a.C, a.C, lane);
+    if (a.dy_lo) row_store<NV, TL>(db, reinterpret_cast<TL*>(a.dy_lo) + (size_t)m * a.C, a.C, lane);
+  }
+  // reduce the 4 waves' column partials through LDS, fixed order
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wid][(i * 64 + lane) * 4 + e] = dlam.v[i][e];
+  if (lane == 0) red[wid][NV * 256] = dskip_acc;
+  __syncthreads();
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < ROW_WAVES; ++w) s += red[w][c];
+    a.part_dlam[(size_t)blockIdx.x * a.C + c] = s;
+  }
+  if (a.skip_x && threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < ROW_WAVES; ++w) s += red[w][NV * 256];
+    a.part_dskip[blockIdx.x] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------ q/k normalise
+struct QkArgs {
+  const void *q, *k, *v;
+  int ldq, ldk, ldv;
+  const float* sqk;
+  float c_q;
+  void *qh, *kh, *vh;
+  float *rq, *rk;
+  int B, T, H, d;
+};
+
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void qknorm_fwd_kernel(QkArgs a) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int C = a.H * a.d, M = a.B * a.T, G = a.d >> 2;  // lanes per head
+  RowVec<NV> s;
+  row_load<NV, float>(s, a.sqk, C, lane);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s.v[i] = s.v[i] * a.c_q;
+  for (int m = blockIdx.x * ROW_WAVES + wid; m < M; m += gridDim.x * ROW_WAVES) {
+    const int b = m / a.T, t = m % a.T;
+    RowVec<NV> q, k, v;
+    row_load<NV, T>(q, reinterpret_cast<const T*>(a.q) + (size_t)m * a.ldq, C, lane);
+    row_load<NV, T>(k, reinterpret_cast<const T*>(a.k) + (size_t)m * a.ldk, C, lane);
+    row_load<NV, T>(v, reinterpret_cast<const T*>(a.v) + (size_t)m * a.ldv, C, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      float sq = q.v[i][0] * q.v[i][0] + q.v[i][1] * q.v[i][1] + q.v[i][2] * q.v[i][2] + q.v[i][3] * q.v[i][3];
+      float sk = k.v[i][0] * k.v[i][0] + k.v[i][1] * k.v[i][1] + k.v[i][2] * k.v[i][2] + k.v[i][3] * k.v[i][3];
+      sq = group_sum_dyn(sq, G);
+      sk = group_sum_dyn(sk, G);
+      if (c < C) {
+        const float rq = 1.0f / sqrtf(sq), rk = 1.0f / sqrtf(sk);
+        const int h = c / a.d, j = c % a.d;
+        const size_t dst = (((size_t)b * a.H + h) * a.T + t) * a.d + j;
+        store4<T>(reinterpret_cast<T*>(a.qh) + dst, q.v[i] * rq * s.v[i]);
+        store4<T>(reinterpret_cast<T*>(a.kh) + dst, k.v[i] * rk * s.v[i]);
+        store4<T>(reinterpret_cast<T*>(a.vh) + dst, v.v[i]);
+        if (j == 0) {
+          a.rq[(size_t)m * a.H + h] = rq;
+          a.rk[(size_t)m * a.H + h] = rk;
+        }
+      }
+    }
+  }
+}
+
+struct QkBwdArgs {
+  const void *dqh, *dkh, *dvh, *qh, *kh;
+  const float *rq, *rk, *sqk;
+  float c_q;
+  void *dq, *dk, *dv;
+  int ldq, ldk, ldv;
+  float* part;
+  int B, T, H, d;
+};
+
+template <int NV, typename T>
+__global__ __launch_bounds__(256) void qknorm_bwd_kernel(QkBwdArgs a) {
+  __shared__ float red[ROW_WAVES][NV * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int C = a.H * a.d, M = a.B * a.T, G = a.d >> 2;
+  RowVec<NV> s, sinv, ds;
+  row_load<NV, float>(s, a.sqk, C, lane);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    s.v[i] = s.v[i] * a.c_q;
+    ds.v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sinv.v[i][e] = s.v[i][e] != 0.f ? 1.0f / s.v[i][e] : 0.f;
+  }
+  for (int m = blockIdx.x * ROW_WAVES + wid; m < M; m += gridDim.x * ROW_WAVES) {
+    const int b = m / a.T, t = m % a.T;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      const bool ok = c < C;
+      const int h = ok ? c / a.d : 0, j = ok ? c % a.d : 0;
+      const size_t src = (((size_t)b * a.H + h) * a.T + t) * a.d + j;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 gq = ok ? load4<T>(reinterpret_cast<const T*>(a.dqh) + src) : z;
+      const f32x4 gk = ok ? load4<T>(reinterpret_cast<const T*>(a.dkh) + src) : z;
+      const f32x4 nq = ok ? load4<T>(reinterpret_cast<const T*>(a.qh) + src) * sinv.v[i] : z;  // unit vector
+      const f32x4 nk = ok ? load4<T>(reinterpret_cast<const T*>(a.kh) + src) * sinv.v[i] : z;
+      ds.v[i] += gq * nq + gk * nk;
+      const f32x4 sgq = gq * s.v[i], sgk = gk * s.v[i];
+      float dq_ = sgq[0] * nq[0] + sgq[1] * nq[1] + sgq[2] * nq[2] + sgq[3] * nq[3];
+      float dk_ = sgk[0] * nk[0] + sgk[1] * nk[1] + sgk[2] * nk[2] + sgk[3] * nk[3];
+      dq_ = group_sum_dyn(dq_, G);
+      dk_ = group_sum_dyn(dk_, G);
+      if (ok) {
+        const float rq = a.rq[(size_t)m * a.H + h], rk = a.rk[(size_t)m * a.H + h];
+        store4<T>(reinterpret_cast<T*>(a.dq) + (size_t)m * a.ldq + c, (sgq - nq * dq_) * rq);
+        store4<T>(reinterpret_cast<T*>(a.dk) + (size_t)m * a.ldk + c, (sgk - nk * dk_) * rk);
+        store4<T>(reinterpret_cast<T*>(a.dv) + (size_t)m * a.ldv + c,
+                  load4<T>(reinterpret_cast<const T*>(a.dvh) + src));
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wid][(i * 64 + lane) * 4 + e] = ds.v[i][e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < ROW_WAVES; ++w) t += red[w][c];
+    a.part[(size_t)blockIdx.x * C + c] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------ SwiGLU
+// thread owns 4 consecutive output columns j..j+3 (inside one 16-group), loops over a row range.
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* uv, const float* suv, float gscale, T* x, int M,
+                                                          int F, int rows_per_blk) {
+  const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (j >= F) return;
+  const int q = j >> 4, w = j & 15;
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+  const f32x4 gu = suv ? *reinterpret_cast<const f32x4*>(suv + j) * gscale : one;
+  const f32x4 gv = suv ? *reinterpret_cast<const f32x4*>(suv + F + j) * gscale : one;
+  const int r0 = blockIdx.y * rows_per_blk;
+  const int r1 = min(M, r0 + rows_per_blk);
+  for (int m = r0; m < r1; ++m) {
+    const T* row = uv + (size_t)m * 2 * F + q * 32 + w;
+    const f32x4 u = load4<T>(row) * gu;
+    const f32x4 v = load4<T>(row + 16) * gv;
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = u[e] * (v[e] * sigmoidf_(v[e]));
+    store4<T>(x + (size_t)m * F + j, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* dx, const T* uv, const float* suv, float gscale,
+                                                          T* duv, float* part, int M, int F, int rows_per_blk) {
+  const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (j >= F) return;
+  const int q = j >> 4, w = j & 15;
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+  const f32x4 gu = suv ? *reinterpret_cast<const f32x4*>(suv + j) * gscale : one;
+  const f32x4 gv = suv ? *reinterpret_cast<const f32x4*>(suv + F + j) * gscale : one;
+  f32x4 dgu = {0.f, 0.f, 0.f, 0.f}, dgv = {0.f, 0.f, 0.f, 0.f};
+  const int r0 = blockIdx.y * rows_per_blk;
+  const int r1 = min(M, r0 + rows_per_blk);
+  for (int m = r0; m < r1; ++m) {
+    const size_t off = (size_t)m * 2 * F + q * 32 + w;
+    const f32x4 ur = load4<T>(uv + off), vr = load4<T>(uv + off + 16);
+    const f32x4 g = load4<T>(dx + (size_t)m * F + j);
+    const f32x4 u = ur * gu, v = vr * gv;
+    f32x4 du, dv;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float sg = sigmoidf_(v[e]);
+      du[e] = g[e] * v[e] * sg;
+      dv[e] = g[e] * u[e] * sg * (1.0f + v[e] * (1.0f - sg));
+    }
+    dgu += du * ur;
+    dgv += dv * vr;
+    store4<T>(duv + off, du * gu);
+    store4<T>(duv + off + 16, dv * gv);
+  }
+  if (part) {
+    float* p = part + (size_t)blockIdx.y * 2 * F;
+    *reinterpret_cast<f32x4*>(p + j) = dgu * gscale;
+    *reinterpret_cast<f32x4*>(p + F + j) = dgv * gscale;
+  }
+}
+
+// ------------------------------------------------------------------------------ small reductions
+__global__ void colsum_reduce_kernel(const float* part, int nblk, int N, float* out, int accumulate, int kind,
+                                     const float* ref, float scale) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * N + n];
+  if (kind == 1) {
+    const float r = ref[n] * scale;
+    s = s * (r > 0.f ? scale : (r < 0.f ? -scale : 0.f));
+  } else {
+    s *= scale;
+  }
+  int dst = n;
+  if (kind == 2) {
+    const int q = n >> 5, w = n & 31, F = N >> 1;
+    dst = w < 16 ? q * 16 + w : F + q * 16 + (w - 16);
+  }
+  out[dst] = accumulate ? out[dst] + s : s;
+}
+
+template <typename TA, typename TB>
+__global__ void colsum_kernel(const TA* a, int lda, const TB* b, int ldb, int R, int N, int period, float* out,
+                              int accumulate, float scale) {
+  // one thread per output element (row class rc in [0,period), column n); loops rows r = rc, rc+period, ...
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int rc = blockIdx.y;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int r = rc; r < R; r += period) {
+    float v = ld1<TA>(a + (size_t)r * lda + n);
+    if (b) v *= ld1<TB>(b + (size_t)r * ldb + n);
+    s += v;
+  }
+  s *= scale;
+  float* o = out + (size_t)rc * N + n;
+  *o = accumulate ? *o + s : s;
+}
+
+template <typename T>
+__global__ void cast_kernel(const float* src, T* dst, long long n4) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    store4<T>(dst + i * 4, *reinterpret_cast<const f32x4*>(src + i * 4));
+}
+
+template <typename T>
+__global__ void scale_cols_kernel(const float* a, int lda, const float* s, float c, T* out, int ldo, int R, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (n >= N || r >= R) return;
+  st1<T>(out + (size_t)r * ldo + n, a[(size_t)r * lda + n] * s[n] * c);
+}
+
+int row_grid(int M) {
+  int blocks = cdiv(M, ROW_WAVES);
+  return blocks > 2048 ? 2048 : blocks;
+}
+
+}  // namespace
+
+#define DISPATCH_NV(C, ...)                     \
+  do {                                          \
+    if ((C) <= 256) { constexpr int NV = 1; __VA_ARGS__; }       \
+    else if ((C) <= 512) { constexpr int NV = 2; __VA_ARGS__; }  \
+    else if ((C) <= 768) { constexpr int NV = 3; __VA_ARGS__; }  \
+    else if ((C) <= 1024) { constexpr int NV = 4; __VA_ARGS__; } \
+    else { constexpr int NV = 8; __VA_ARGS__; }                  \
+  } while (0)
+
+extern "C" int nvit_lerp_fwd(int dt, const float* h, const void* y, int y_dt, const float* alpha, float c_a,
+                             const float* skip_x, const float* skip, float* out, void* out_lo, int M, int C,
+                             void* stream) {
+  NVIT_REQUIRE(C % 4 == 0 && C <= 2048 && M > 0, "lerp_fwd: C=%d must be a multiple of 4 and <= 2048", C);
+  NVIT_REQUIRE(!skip_x || skip, "lerp_fwd: skip_x without skip");
+  LerpFwdArgs a{h, y, alpha, c_a, skip_x, skip, out, out_lo, M, C};
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = row_grid(M);
+  ProfScope ps(NVIT_KID_ROWOPS, 0.0, (double)M * C * (skip_x ? 16.0 : 12.0), s);
+  DISPATCH_NV(C, {
+    if (y_dt == NVIT_F32 && dt == NVIT_F32)
+      hipLaunchKernelGGL((lerp_fwd_kernel<NV, float, float>), dim3(grid), dim3(256), 0, s, a);
+    else if (y_dt == NVIT_F32)
+      hipLaunchKernelGGL((lerp_fwd_kernel<NV, float, bf16>), dim3(grid), dim3(256), 0, s, a);
+    else if (dt == NVIT_F32)
+      hipLaunchKernelGGL((lerp_fwd_kernel<NV, bf16, float>), dim3(grid), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((lerp_fwd_kernel<NV, bf16, bf16>), dim3(grid), dim3(256), 0, s, a);
+  });
+  NVIT_CHECK_LAUNCH("lerp_fwd");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_lerp_bwd(int dt, const float* dout, const float* h, const void* y, int y_dt, const float* alpha,
+                             float c_a, const float* skip_x, const float* skip, float* dh, int accum_dh, float* dy,
+                             void* dy_lo, float* dskip_x, float* part_dlam, float* part_dskip, int nblk, int M,
+                             int C, void* stream) {
+  NVIT_REQUIRE(C % 4 == 0 && C <= 2048 && M > 0, "lerp_bwd: C=%d must be a multiple of 4 and <= 2048", C);
+  NVIT_REQUIRE(nblk > 0 && nblk <= 4096, "lerp_bwd: nblk out of range");
+  NVIT_REQUIRE(!skip_x || (skip && dskip_x && part_dskip), "lerp_bwd: skip buffers missing");
+  LerpBwdArgs a{dout, h, y, alpha, c_a, skip_x, skip, dh, accum_dh, dy, dy_lo, dskip_x, part_dlam, part_dskip, M, C};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(NVIT_KID_ROWOPS, 0.0, (double)M * C * 24.0, s);
+  DISPATCH_NV(C, {
+    if (y_dt == NVIT_F32 && dt == NVIT_F32)
+      hipLaunchKernelGGL((lerp_bwd_kernel<NV, float, float>), dim3(nblk), dim3(256), 0, s, a);
+    else if (y_dt == NVIT_F32)
+      hipLaunchKernelGGL((lerp_bwd_kernel<NV, float, bf16>), dim3(nblk), dim3(256), 0, s, a);
+    else if (dt == NVIT_F32)
+      hipLaunchKernelGGL((lerp_bwd_kernel<NV, bf16, float>), dim3(nblk), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((lerp_bwd_kernel<NV, bf16, bf16>), dim3(nblk), dim3(256), 0, s, a);
+  });
+  NVIT_CHECK_LAUNCH("lerp_bwd");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_qknorm_fwd(int dt, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                               const float* sqk, float c_q, void* qh, void* kh, void* vh, float* rq, float* rk,
+                               int B, int T, int H, int d, void* stream) {
+  const int C = H * d;
+  NVIT_REQUIRE(d == 16 || d == 32 || d == 64 || d == 128, "qknorm_fwd: head dim %d unsupported", d);
+  NVIT_REQUIRE(C <= 2048 && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "qknorm_fwd: bad C/ld");
+  QkArgs a{q, k, v, ldq, ldk, ldv, sqk, c_q, qh, kh, vh, rq, rk, B, T, H, d};
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = row_grid(B * T);
+  ProfScope ps(NVIT_KID_ROWOPS, 0.0, (double)B * T * C * (dt == NVIT_F32 ? 24.0 : 12.0), s);
+  DISPATCH_NV(C, {
+    if (dt == NVIT_F32)
+      hipLaunchKernelGGL((qknorm_fwd_kernel<NV, float>), dim3(grid), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((qknorm_fwd_kernel<NV, bf16>), dim3(grid), dim3(256), 0, s, a);
+  });
+  NVIT_CHECK_LAUNCH("qknorm_fwd");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_qknorm_bwd(int dt, const void* dqh, const void* dkh, const void* dvh, const void* qh,
+                               const void* kh, const float* rq, const float* rk, const float* sqk, float c_q,
+                               void* dq, int ldq, void* dk, int ldk, void* dv, int ldv, float* part_dsqk, int nblk,
+                               int B, int T, int H, int d, void* stream) {
+  const int C = H * d;
+  NVIT_REQUIRE(d == 16 || d == 32 || d == 64 || d == 128, "qknorm_bwd: head dim %d unsupported", d);
+  NVIT_REQUIRE(C <= 2048 && ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0, "qknorm_bwd: bad C/ld");
+  NVIT_REQUIRE(nblk > 0 && nblk <= 4096, "qknorm_bwd: nblk out of range");
+  QkBwdArgs a{dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q, dq, dk, dv, ldq, ldk, ldv, part_dsqk, B, T, H, d};
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(NVIT_KID_ROWOPS, 0.0, (double)B * T * C * (dt == NVIT_F32 ? 32.0 : 16.0), s);
+  DISPATCH_NV(C, {
+    if (dt == NVIT_F32)
+      hipLaunchKernelGGL((qknorm_bwd_kernel<NV, float>), dim3(nblk), dim3(256), 0, s, a);
+    else
+      hipLaunchKernelGGL((qknorm_bwd_kernel<NV, bf16>), dim3(nblk), dim3(256), 0, s, a);
+  });
+  NVIT_CHECK_LAUNCH("qknorm_bwd");
+  return NVIT_OK;
+}
+
+static int swiglu_rows_per_blk(int M, int F) {
+  const int colblocks = cdiv(F, 1024);
+  int rowblocks = cdiv(2048, colblocks);
+  int rpb = cdiv(M, rowblocks);
+  return rpb < 1 ? 1 : rpb;
+}
+
+extern "C" int nvit_swiglu_fwd(int dt, const void* uv, const float* suv, float gscale, void* x, int M, int F,
+                               void* stream) {
+  NVIT_REQUIRE(F % 16 == 0 && M > 0, "swiglu_fwd: F=%d must be a multiple of 16", F);
+  hipStream_t s = (hipStream_t)stream;
+  const int rpb = swiglu_rows_per_blk(M, F);
+  dim3 grid(cdiv(F, 1024), cdiv(M, rpb));
+  ProfScope ps(NVIT_KID_ROWOPS, 0.0, (double)M * F * 3.0 * (dt == NVIT_F32 ? 4 : 2), s);
+  if (dt == NVIT_F32)
+    hipLaunchKernelGGL(swiglu_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)uv, suv, gscale, (float*)x, M, F, rpb);
+  else
+    hipLaunchKernelGGL(swiglu_fwd_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)uv, suv, gscale, (bf16*)x, M, F, rpb);
+  NVIT_CHECK_LAUNCH("swiglu_fwd");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_swiglu_bwd(int dt, const void* dx, const void* uv, const float* suv, float gscale, void* duv,
+                               float* part_dsuv, int rows_per_blk, int M, int F, void* stream) {
+  NVIT_REQUIRE(F % 16 == 0 && M > 0 && rows_per_blk > 0, "swiglu_bwd: bad shape");
+  NVIT_REQUIRE(!suv || part_dsuv, "swiglu_bwd: part_dsuv missing");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(F, 1024), cdiv(M, rows_per_blk));
+  ProfScope ps(NVIT_KID_ROWOPS, 0.0, (double)M * F * 5.0 * (dt == NVIT_F32 ? 4 : 2), s);
+  if (dt == NVIT_F32)
+    hipLaunchKernelGGL(swiglu_bwd_kernel<float>, grid, dim3(256), 0, s, (const float*)dx, (const float*)uv, suv, gscale,
+                       (float*)duv, suv ? part_dsuv : nullptr, M, F, rows_per_blk);
+  else
+    hipLaunchKernelGGL(swiglu_bwd_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)dx, (const bf16*)uv, suv, gscale,
+                       (bf16*)duv, suv ? part_dsuv : nullptr, M, F, rows_per_blk);
+  NVIT_CHECK_LAUNCH("swiglu_bwd");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_colsum_reduce(const float* part, int nblk, int N, float* out, int accumulate, int kind,
+                                  const float* ref, float scale, void* stream) {
+  NVIT_REQUIRE(kind == 0 || (kind == 1 && ref) || (kind == 2 && N % 32 == 0), "colsum_reduce: bad kind");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 128)), dim3(128), 0, s, part, nblk, N, out, accumulate, kind,
+                     ref, scale);
+  NVIT_CHECK_LAUNCH("colsum_reduce");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_colsum(const void* a, int a_dt, int lda, const void* b, int b_dt, int ldb, int R, int N,
+                           int period, float* out, int accumulate, float scale, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int per = period > 0 ? period : 1;
+  dim3 grid(cdiv(N, 128), per);
+#define CS(TA, TB) \
+  hipLaunchKernelGGL((colsum_kernel<TA, TB>), grid, dim3(128), 0, s, (const TA*)a, lda, (const TB*)b, ldb, R, N, per, out, accumulate, scale)
+  if (a_dt == NVIT_F32 && (b_dt == NVIT_F32 || !b)) CS(float, float);
+  else if (a_dt == NVIT_F32) CS(float, bf16);
+  else if (b_dt == NVIT_F32 || !b) CS(bf16, float);
+  else CS(bf16, bf16);
+#undef CS
+  NVIT_CHECK_LAUNCH("colsum");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_cast(const float* src, void* dst, int dt, int64_t n, void* stream) {
+  NVIT_REQUIRE(n % 4 == 0, "cast: n must be a multiple of 4");
+  hipStream_t s = (hipStream_t)stream;
+  const long long n4 = n / 4;
+  int blocks = cdiv(n4, 256);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) return NVIT_OK;
+  if (dt == NVIT_F32)
+    hipLaunchKernelGGL(cast_kernel<float>, dim3(blocks), dim3(256), 0, s, src, (float*)dst, n4);
+  else
+    hipLaunchKernelGGL(cast_kernel<bf16>, dim3(blocks), dim3(256), 0, s, src, (bf16*)dst, n4);
+  NVIT_CHECK_LAUNCH("cast");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_scale_cols(const float* a, int lda, const float* sc, float c, void* out, int out_dt, int ldo,
+                               int R, int N, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(cdiv(N, 128), R);
+  if (out_dt == NVIT_F32)
+    hipLaunchKernelGGL(scale_cols_kernel<float>, grid, dim3(128), 0, s, a, lda, sc, c, (float*)out, ldo, R, N);
+  else
+    hipLaunchKernelGGL(scale_cols_kernel<bf16>, grid, dim3(128), 0, s, a, lda, sc, c, (bf16*)out, ldo, R, N);
+  NVIT_CHECK_LAUNCH("scale_cols");
+  return NVIT_OK;
+}

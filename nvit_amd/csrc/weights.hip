@@ -1,0 +1,172 @@
+// Weight maintenance kernels.
+//
+// renorm_kernel: Trainer.normalize_matrices (/root/reference/nvit/train.py:461-480) as ONE
+// persistent launch over a device-side table of matrices.  fp32, in place, algorithmic
+// minimum traffic (one HBM read + one write per element):
+//   dim=1 (row norms, query/key/value/c_fc): one wave per row; the second pass over the row
+//         (<= 16 KiB) is served by L1/L2.
+//   dim=0 (column norms, att_c_proj/mlp_c_proj): a workgroup keeps a [rows x 32-column] slab
+//         in LDS (<= 144 KiB of the CU's 160 KiB), so the column pass needs no re-read.
+//
+// shadow_kernel: builds the private MFMA-operand copies of the fp32 masters: W (optionally
+// row-permuted for the SwiGLU interleave) and W^T, cast to bf16 (or kept fp32 for the exact
+// mode), zero padded to the requested leading dimensions.
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void renorm_kernel(const int64_t* table, int n, int total_items) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
+    int mi = 0;
+    for (int i = 1; i < n; ++i) {
+      if (item >= (int)table[i * 5 + 4]) mi = i; else break;
+    }
+    float* W = reinterpret_cast<float*>(table[mi * 5 + 0]);
+    const int rows = (int)table[mi * 5 + 1], cols = (int)table[mi * 5 + 2], dim = (int)table[mi * 5 + 3];
+    const int local = item - (int)table[mi * 5 + 4];
+    if (dim == 1) {
+      const int r0 = local * NVIT_RENORM_ROWS_PER_ITEM;
+      for (int rr = wid; rr < NVIT_RENORM_ROWS_PER_ITEM; rr += 4) {
+        const int r = r0 + rr;
+        if (r >= rows) break;
+        float* row = W + (size_t)r * cols;
+        float s = 0.f;
+        if ((cols & 3) == 0) {
+          for (int c = lane * 4; c < cols; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+          }
+          s = wave_sum(s);
+          const float nrm = sqrtf(s);
+          for (int c = lane * 4; c < cols; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+            *reinterpret_cast<f32x4*>(row + c) = v / nrm;
+          }
+        } else {
+          for (int c = lane; c < cols; c += 64) s += row[c] * row[c];
+          s = wave_sum(s);
+          const float nrm = sqrtf(s);
+          for (int c = lane; c < cols; c += 64) row[c] = row[c] / nrm;
+        }
+      }
+    } else {
+      // column slab [rows][32] in LDS
+      float* slab = reinterpret_cast<float*>(smem);
+      float* red = slab + (size_t)rows * NVIT_RENORM_COLS_PER_ITEM;  // [32][32]
+      const int c0 = local * NVIT_RENORM_COLS_PER_ITEM;
+      const int cg = (tid & 7) * 4, rg = tid >> 3;  // 8 threads cover 32 columns; 32 row groups
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int r = rg; r < rows; r += 32) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c0 + cg + 3 < cols)
+          v = *reinterpret_cast<const f32x4*>(W + (size_t)r * cols + c0 + cg);
+        else
+          for (int e = 0; e < 4; ++e)
+            if (c0 + cg + e < cols) v[e] = W[(size_t)r * cols + c0 + cg + e];
+        *reinterpret_cast<f32x4*>(slab + r * 32 + cg) = v;
+        acc += v * v;
+      }
+      *reinterpret_cast<f32x4*>(red + rg * 32 + cg) = acc;
+      __syncthreads();
+      if (tid < 32) {
+        float s = 0.f;
+        for (int g = 0; g < 32; ++g) s += red[g * 32 + tid];
+        red[tid] = sqrtf(s);  // row 0 of red is only read by thread `tid` above before this write
+      }
+      __syncthreads();
+      const f32x4 nrm = *reinterpret_cast<const f32x4*>(red + cg);
+      for (int r = rg; r < rows; r += 32) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(slab + r * 32 + cg);
+        v = v / nrm;
+        if (c0 + cg + 3 < cols)
+          *reinterpret_cast<f32x4*>(W + (size_t)r * cols + c0 + cg) = v;
+        else
+          for (int e = 0; e < 4; ++e)
+            if (c0 + cg + e < cols) W[(size_t)r * cols + c0 + cg + e] = v[e];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__device__ __forceinline__ int shadow_perm_row(int perm, int s, int F) {
+  if (perm == 0) return s;
+  const int q = s >> 5, w = s & 31;
+  return w < 16 ? q * 16 + w : F + q * 16 + (w - 16);
+}
+
+// table row: {src, rows, cols, dst, dst_ld, dst_cols, dstT, dstT_ld, dstT_cols, perm, first_item, tiles_c}
+template <typename T>
+__global__ __launch_bounds__(256) void shadow_kernel(const int64_t* table, int n, int total_items) {
+  __shared__ float tile[64][65];
+  const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+  for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
+    int mi = 0;
+    for (int i = 1; i < n; ++i) {
+      if (item >= (int)table[i * 12 + 10]) mi = i; else break;
+    }
+    const int64_t* e = table + mi * 12;
+    const float* src = reinterpret_cast<const float*>(e[0]);
+    const int rows = (int)e[1], cols = (int)e[2];
+    T* dst = reinterpret_cast<T*>(e[3]);
+    const int dst_ld = (int)e[4], dst_cols = (int)e[5];
+    T* dstT = reinterpret_cast<T*>(e[6]);
+    const int dstT_ld = (int)e[7], dstT_cols = (int)e[8];
+    const int perm = (int)e[9];
+    const int local = item - (int)e[10], tiles_c = (int)e[11];
+    const int r0 = (local / tiles_c) * 64, c0 = (local % tiles_c) * 64;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int r = r0 + ty + 4 * i, c = c0 + tx;
+      float v = 0.f;
+      if (r < rows && c < cols) v = src[(size_t)shadow_perm_row(perm, r, rows / 2) * cols + c];
+      tile[ty + 4 * i][tx] = v;
+      if (dst && r < rows && c < dst_cols) dst[(size_t)r * dst_ld + c] = (T)v;
+    }
+    __syncthreads();
+    if (dstT) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < cols && r < dstT_cols) dstT[(size_t)c * dstT_ld + r] = (T)tile[tx][ty + 4 * i];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace
+
+extern "C" int nvit_renorm_weights(const int64_t* table, int n, int total_items, void* stream) {
+  NVIT_REQUIRE(n > 0 && total_items > 0, "renorm: empty table");
+  hipStream_t s = (hipStream_t)stream;
+  // LDS for the largest column slab: caller guarantees rows <= 1152 for dim=0 matrices.
+  static const int kMaxLds = 1152 * NVIT_RENORM_COLS_PER_ITEM * 4 + 32 * 32 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)renorm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
+    if (e != hipSuccess) NVIT_FAIL((int)e, "renorm: cannot raise LDS limit: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  int grid = total_items < 1024 ? total_items : 1024;
+  ProfScope ps(NVIT_KID_RENORM, 0.0, 0.0, s);
+  hipLaunchKernelGGL(renorm_kernel, dim3(grid), dim3(256), kMaxLds, s, table, n, total_items);
+  NVIT_CHECK_LAUNCH("renorm");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_shadow_weights(const int64_t* table, int n, int total_items, int dt, void* stream) {
+  NVIT_REQUIRE(n > 0 && total_items > 0, "shadow: empty table");
+  NVIT_REQUIRE(dt == NVIT_F32 || dt == NVIT_BF16, "shadow: bad dt");
+  hipStream_t s = (hipStream_t)stream;
+  int grid = total_items < 4096 ? total_items : 4096;
+  ProfScope ps(NVIT_KID_SHADOW, 0.0, 0.0, s);
+  if (dt == NVIT_F32)
+    hipLaunchKernelGGL(shadow_kernel<float>, dim3(grid), dim3(256), 0, s, table, n, total_items);
+  else
+    hipLaunchKernelGGL(shadow_kernel<bf16>, dim3(grid), dim3(256), 0, s, table, n, total_items);
+  NVIT_CHECK_LAUNCH("shadow");
+  return NVIT_OK;
+}

@@ -1,0 +1,694 @@
+"""nViT model whose forward/backward run on hand-written gfx950 HIP kernels.
+
+Drop-in mirror of the reference module tree (/root/reference/nvit/model.py): same class
+names, constructor and forward() signatures, parameter names and shapes (SURVEY.md §8b,
+§9.5), so `ViT(ViTConfig(**model_args))`, `state_dict()/load_state_dict()`,
+`configure_optimizers()` and the attribute accesses of the reference trainer
+(train.py:422,474-480,1045-1054) work unchanged.  The nn.Conv2d / nn.Linear / nn.LayerNorm
+sub-modules are parameter containers only: their torch forward is never called.  All
+compute goes through the C ABI in include/nvit_hip.h (nvit_amd/ops.py); there is no CPU
+or torch-operator fallback — without the HIP library or a GPU, forward() raises.
+
+Only the nViT path (`use_nvit=True`, SDPA semantics, `flash_attn` ignored) is implemented;
+the reference's non-nViT path crashes upstream and its flash_attn=True
+branch attends over the wrong axis (Q3).
+
+Precision modes (model.precision): "bf16" = bf16 MFMA operands, fp32 accumulate, fp32
+residual stream/norms/params/grads (the performance mode); "fp32" = exact-f32 MFMA
+everywhere (parity mode, <=1e-5 against the CPU oracle).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import BF16, F32
+from .config import ViTConfig
+
+Tensor = torch.Tensor
+
+
+def _dt_from_precision(p: str) -> int:
+    if p == "fp32":
+        return F32
+    if p == "bf16":
+        return BF16
+    raise ValueError(f"precision must be 'fp32' or 'bf16', got {p!r}")
+
+
+class RMSNorm(nn.Module):
+    """Parameter container only (reference model.py:172-184; dead in nViT mode, kept for state_dict parity)."""
+
+    def __init__(self, embdim: int, eps: float = 1e-6) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(embdim))
+        self.eps = eps
+
+    def forward(self, x: Tensor) -> Tensor:
+        raise RuntimeError("RMSNorm is only reachable on the reference's non-nViT path, which is out of scope")
+
+
+# --------------------------------------------------------------------------------------------
+# Runtime: precision, shadows (MFMA-operand copies of the fp32 master weights)
+# --------------------------------------------------------------------------------------------
+class _Runtime:
+    """Per-model device state that is NOT part of the state_dict: bf16 (or fp32) weight shadows in
+    the layouts the GEMMs want, rebuilt from the fp32 masters at the start of every forward."""
+
+    def __init__(self, model: "ViT") -> None:
+        self.model = model
+        self.dt = F32
+        self.device = None
+        self.key = None
+        self.sh: Dict[str, Tensor] = {}
+        self.table = None
+        self.items = 0
+        self.btable = None
+        self.bitems = 0
+
+    def _build(self, device, dt: int) -> None:
+        m, cfg = self.model, self.model.config
+        C, L = cfg.n_embd, cfg.n_layer
+        td = ops.tdtype(dt)
+        bk = ops.bk_of(dt)
+        sh: Dict[str, Tensor] = {}
+        ent = []   # weight shadows (type dt)
+        bent = []  # bias shadows (fp32)
+
+        def new(name, r, c):
+            t = torch.empty((r, c), device=device, dtype=td)
+            sh[name] = t
+            return t
+
+        def newb(name, n):
+            t = torch.empty((n,), device=device, dtype=torch.float32)
+            sh[name] = t
+            return t
+
+        def w2(p):  # 2-D view of a parameter
+            return p.detach().reshape(p.shape[0], -1)
+
+        Kl = cfg.channels * cfg.local_patch_size ** 2
+        Kg = cfg.channels * cfg.global_patch_size ** 2
+        ent.append((w2(m.local_patch_embed.weight), new("pe_l", C, Kl), Kl, Kl, None, 0, 0, 0))
+        ent.append((w2(m.global_patch_embed[1].weight), new("pe_g", C, Kg), Kg, Kg, None, 0, 0, 0))
+
+        def stack(prefix, lins, perm=0):
+            """shadow of row-stacked Linear weights [sum rows, K] and its transpose [K, sum rows]."""
+            rows = sum(l.weight.shape[0] for l in lins)
+            K = lins[0].weight.shape[1]
+            W = new(prefix + ".W", rows, K)
+            Wt = new(prefix + ".Wt", K, rows)
+            off = 0
+            for l in lins:
+                r = l.weight.shape[0]
+                ent.append((w2(l.weight), W[off:], K, K, Wt[:, off:], rows, r, perm))
+                off += r
+            if lins[0].bias is not None:
+                bsh = newb(prefix + ".b", rows)
+                off = 0
+                for l in lins:
+                    r = l.weight.shape[0]
+                    bent.append((l.bias.detach().reshape(r, 1), bsh[off:], 1, 1, None, 0, 0, perm))
+                    off += r
+
+        ca = m.cross_attention
+        stack("x.q", [ca.q_local])
+        stack("x.kv", [ca.k_global, ca.v_global])
+        stack("x.proj", [ca.proj], perm=1)
+        stack("x.out", [ca.out_proj])
+        for i, blk in enumerate(m.transformer.h):
+            stack(f"h{i}.qkv", [blk.query, blk.key, blk.value])
+            stack(f"h{i}.o", [blk.att_c_proj])
+            stack(f"h{i}.fc", [blk.c_fc], perm=1)
+            stack(f"h{i}.p", [blk.mlp_c_proj])
+        # classifier head: transposed shadow zero-padded along classes to a multiple of the K stage
+        ncls = cfg.num_classes
+        Kp = ops.round_up(ncls, bk)
+        ent.append((w2(m.mlp_head[1].weight), new("head.W", ncls, C), C, C, new("head.Wt", C, Kp), Kp, Kp, 0))
+        ent.append((w2(m.reconstruction_head[0].weight), new("rec.W", Kl, C), C, C, new("rec.Wt", C, Kl), Kl, Kl, 0))
+        self.sh = sh
+        self.table, self.items = ops.shadow_table(ent, device)
+        if bent:
+            self.btable, self.bitems = ops.shadow_table(bent, device)
+        else:
+            self.btable, self.bitems = None, 0
+
+    def refresh(self, device, dt: int) -> None:
+        key = (str(device), dt) + tuple(p.data_ptr() for p in self.model.parameters())
+        if key != self.key:
+            self._build(device, dt)
+            self.key, self.device, self.dt = key, device, dt
+        ops.shadow_weights(self.table, self.items, dt)
+        if self.btable is not None:
+            ops.shadow_weights(self.btable, self.bitems, F32)
+
+
+# --------------------------------------------------------------------------------------------
+# Functional forward / backward pieces (all compute through ops.*)
+# --------------------------------------------------------------------------------------------
+def _attn_part_fwd(rt: _Runtime, impl: int, q_src, ldq, k_src, ldk, v_src, ldv, sqk, c_q, B, T, H, d):
+    qh, kh, vh, rq, rk = ops.qknorm_fwd(rt.dt, q_src, ldq, k_src, ldk, v_src, ldv, sqk, c_q, B, T, H, d)
+    o, lse = ops.attn_fwd(rt.dt, impl, qh, kh, vh, math.sqrt(d))
+    return qh, kh, vh, rq, rk, o, lse
+
+
+def _param_grad_alpha(part: Tensor, alpha: Tensor, c_a: float) -> Tensor:
+    g = torch.empty_like(alpha)
+    ops.colsum_reduce(part, g, False, kind=1, ref=alpha, scale=c_a)
+    return g
+
+
+def _param_grad_scaled(part: Tensor, like: Tensor, scale: float) -> Tensor:
+    g = torch.empty_like(like)
+    ops.colsum_reduce(part, g, False, kind=0, scale=scale)
+    return g
+
+
+def _bias_grad(dy_lo: Tensor, M: int, N: int, perm: int = 0) -> Tensor:
+    g = torch.empty((N,), device=dy_lo.device, dtype=torch.float32)
+    if perm == 0:
+        ops.colsum_big(dy_lo, M, N, g, False)
+    else:
+        part = torch.empty((512, N), device=dy_lo.device, dtype=torch.float32)
+        ops.colsum(dy_lo, M, N, part, False, period=512)
+        ops.colsum_reduce(part, g, False, kind=2)
+    return g
+
+
+class _BlockFn(torch.autograd.Function):
+    """One nGPT block (+ norm_skip): reference Block.forward (model.py:92-169) followed by
+    Block.norm_skip (model.py:84-87) as called at model.py:450-452."""
+
+    @staticmethod
+    def forward(ctx, x, x_lo, rt, idx, with_skip, impl, skip_param, attn_alpha, mlp_alpha, sqk, suv, wq, wk, wv, wo,
+                wfc, wp, bq, bk_, bv, bo, bfc, bp):
+        cfg = rt.model.config
+        C, H = cfg.n_embd, cfg.n_head
+        d = C // H
+        M = x.shape[0]
+        T = rt.model.n_tokens
+        B = M // T
+        dt, td = rt.dt, ops.tdtype(rt.dt)
+        sh = rt.sh
+        c_q, c_a = 1.0 / cfg.base_scale, 0.05 / cfg.base_scale
+        pre = f"h{idx}."
+        has_b = bq is not None
+        qkv = ops.gemm_nt(x_lo, sh[pre + "qkv.W"], M, 3 * C, C, out_dtype=td, bias=sh.get(pre + "qkv.b"))
+        qh, kh, vh, rq, rk, o, lse = _attn_part_fwd(rt, impl, qkv, 3 * C, qkv[:, C:], 3 * C, qkv[:, 2 * C:], 3 * C,
+                                                     sqk, c_q, B, T, H, d)
+        del qkv
+        y = ops.gemm_nt(o, sh[pre + "o.W"], M, C, C, out_dtype=torch.float32, bias=sh.get(pre + "o.b"))
+        h1, h1_lo = ops.lerp_fwd(dt, x, y, attn_alpha, c_a, want_lo=(dt != F32))
+        if dt == F32:
+            h1_lo = h1
+        uv = ops.gemm_nt(h1_lo, sh[pre + "fc.W"], M, 8 * C, C, out_dtype=td, bias=sh.get(pre + "fc.b"))
+        gscale = math.sqrt(C)
+        xm = ops.swiglu_fwd(dt, uv, suv, gscale, M, 4 * C)
+        y2 = ops.gemm_nt(xm, sh[pre + "p.W"], M, C, 4 * C, out_dtype=torch.float32, bias=sh.get(pre + "p.b"))
+        if with_skip:
+            xn, xn_lo = ops.lerp_fwd(dt, h1, y2, mlp_alpha, c_a, skip_x=x, skip=skip_param, want_lo=(dt != F32))
+        else:
+            xn, xn_lo = ops.lerp_fwd(dt, h1, y2, mlp_alpha, c_a, want_lo=(dt != F32))
+        if dt == F32:
+            xn_lo = xn
+        ctx.rt, ctx.idx, ctx.with_skip, ctx.impl, ctx.has_b = rt, idx, with_skip, impl, has_b
+        ctx.dims = (B, T, C, H, d, M)
+        ctx.save_for_backward(x, x_lo, qh, kh, vh, rq, rk, o, lse, y, h1, h1_lo, uv, xm, y2, skip_param, attn_alpha,
+                              mlp_alpha, sqk, suv)
+        ctx.mark_non_differentiable(xn_lo)
+        return xn, xn_lo
+
+    @staticmethod
+    def backward(ctx, dxn, _unused):
+        (x, x_lo, qh, kh, vh, rq, rk, o, lse, y, h1, h1_lo, uv, xm, y2, skip_param, attn_alpha, mlp_alpha, sqk,
+         suv) = ctx.saved_tensors
+        rt, idx, impl = ctx.rt, ctx.idx, ctx.impl
+        B, T, C, H, d, M = ctx.dims
+        cfg = rt.model.config
+        dt, td = rt.dt, ops.tdtype(rt.dt)
+        sh = rt.sh
+        c_q, c_a = 1.0 / cfg.base_scale, 0.05 / cfg.base_scale
+        pre = f"h{idx}."
+        dxn = dxn.contiguous()
+        # ---- MLP half + norm_skip
+        if ctx.with_skip:
+            dh1, _, dy2_lo, dx, part_lam, part_skip = ops.lerp_bwd(dt, dxn, h1, y2, mlp_alpha, c_a, x, skip_param,
+                                                                   None, False, False, True)
+            dskip = torch.empty_like(skip_param)
+            ops.colsum_reduce(part_skip, dskip, False)
+        else:
+            dh1, _, dy2_lo, _, part_lam, _ = ops.lerp_bwd(dt, dxn, h1, y2, mlp_alpha, c_a, None, None, None, False,
+                                                          False, True)
+            dx, dskip = None, None
+        d_mlp_alpha = _param_grad_alpha(part_lam, mlp_alpha, c_a)
+        dxm = ops.gemm_nt(dy2_lo, sh[pre + "p.Wt"], M, 4 * C, C, out_dtype=td)
+        g_wp = ops.gemm_tn(dy2_lo, xm, torch.empty((C, 4 * C), device=x.device, dtype=torch.float32), M, C, 4 * C)
+        g_bp = _bias_grad(dy2_lo, M, C) if ctx.has_b else None
+        del dy2_lo
+        gscale = math.sqrt(C)
+        duv, part_suv = ops.swiglu_bwd(dt, dxm, uv, suv, gscale, M, 4 * C)
+        del dxm
+        d_suv = _param_grad_scaled(part_suv, suv, 1.0)
+        ops.gemm_nt(duv, sh[pre + "fc.Wt"], M, C, 8 * C, out=dh1, accumulate=True)
+        g_wfc = ops.gemm_tn(duv, h1_lo, torch.empty((8 * C, C), device=x.device, dtype=torch.float32), M, 8 * C, C,
+                            perm=1)
+        g_bfc = _bias_grad(duv, M, 8 * C, perm=1) if ctx.has_b else None
+        del duv
+        # ---- attention half
+        if dx is None:
+            dx, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dh1, x, y, attn_alpha, c_a, None, None, None, False,
+                                                        False, True)
+        else:
+            dx, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dh1, x, y, attn_alpha, c_a, None, None, dx, True, False,
+                                                        True)
+        d_attn_alpha = _param_grad_alpha(part_lam, attn_alpha, c_a)
+        do = ops.gemm_nt(dy_lo, sh[pre + "o.Wt"], M, C, C, out_dtype=td)
+        g_wo = ops.gemm_tn(dy_lo, o, torch.empty((C, C), device=x.device, dtype=torch.float32), M, C, C)
+        g_bo = _bias_grad(dy_lo, M, C) if ctx.has_b else None
+        del dy_lo
+        dqh, dkh, dvh = ops.attn_bwd(dt, impl, do, qh, kh, vh, o, lse, math.sqrt(d))
+        dqkv = torch.empty((M, 3 * C), device=x.device, dtype=td)
+        part_sqk = ops.qknorm_bwd(dt, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q, dqkv, 3 * C, dqkv[:, C:], 3 * C,
+                                  dqkv[:, 2 * C:], 3 * C, B, T, H, d)
+        d_sqk = _param_grad_scaled(part_sqk, sqk, c_q)
+        ops.gemm_nt(dqkv, sh[pre + "qkv.Wt"], M, C, 3 * C, out=dx, accumulate=True)
+        g_qkv = ops.gemm_tn(dqkv, x_lo, torch.empty((3 * C, C), device=x.device, dtype=torch.float32), M, 3 * C, C)
+        g_bqkv = _bias_grad(dqkv, M, 3 * C) if ctx.has_b else None
+        gq, gk, gv = g_qkv[:C], g_qkv[C:2 * C], g_qkv[2 * C:]
+        if ctx.has_b:
+            gbq, gbk, gbv = g_bqkv[:C], g_bqkv[C:2 * C], g_bqkv[2 * C:]
+        else:
+            gbq = gbk = gbv = None
+        return (dx, None, None, None, None, None, dskip, d_attn_alpha, d_mlp_alpha, d_sqk, d_suv, gq, gk, gv, g_wo,
+                g_wfc, g_wp, gbq, gbk, gbv, g_bo, g_bfc, g_bp)
+
+
+class _CrossFn(torch.autograd.Function):
+    """CrossAttentionBlock.forward (reference model.py:219-275), nViT branch."""
+
+    @staticmethod
+    def forward(ctx, loc, glo, rt, impl, attn_alpha, sqk, wq, wk, wv, wproj, wout, bq, bk_, bv, bproj, bout):
+        cfg = rt.model.config
+        C, H = cfg.n_embd, cfg.n_head
+        d = C // H
+        M = loc.shape[0]
+        T = rt.model.n_tokens
+        B = M // T
+        dt, td = rt.dt, ops.tdtype(rt.dt)
+        sh = rt.sh
+        c_q, c_a = 1.0 / cfg.base_scale, 0.05 / cfg.base_scale
+        has_b = bq is not None
+        if dt == F32:
+            loc_lo, glo_lo = loc, glo
+        else:
+            loc_lo, glo_lo = ops.cast(loc, dt), ops.cast(glo, dt)
+        q = ops.gemm_nt(loc_lo, sh["x.q.W"], M, C, C, out_dtype=td, bias=sh.get("x.q.b"))
+        kv = ops.gemm_nt(glo_lo, sh["x.kv.W"], M, 2 * C, C, out_dtype=td, bias=sh.get("x.kv.b"))
+        qh, kh, vh, rq, rk, o, lse = _attn_part_fwd(rt, impl, q, C, kv, 2 * C, kv[:, C:], 2 * C, sqk, c_q, B, T, H, d)
+        del q, kv
+        pr = ops.gemm_nt(o, sh["x.proj.W"], M, 2 * C, C, out_dtype=td, bias=sh.get("x.proj.b"))
+        g = ops.swiglu_fwd(dt, pr, None, 1.0, M, C)
+        y = ops.gemm_nt(g, sh["x.out.W"], M, C, C, out_dtype=torch.float32, bias=sh.get("x.out.b"))
+        x, x_lo = ops.lerp_fwd(dt, loc, y, attn_alpha, c_a, want_lo=(dt != F32))
+        if dt == F32:
+            x_lo = x
+        ctx.rt, ctx.impl, ctx.has_b = rt, impl, has_b
+        ctx.dims = (B, T, C, H, d, M)
+        ctx.save_for_backward(loc, glo, loc_lo, glo_lo, qh, kh, vh, rq, rk, o, lse, pr, g, y, attn_alpha, sqk)
+        ctx.mark_non_differentiable(x_lo)
+        return x, x_lo
+
+    @staticmethod
+    def backward(ctx, dx, _unused):
+        loc, glo, loc_lo, glo_lo, qh, kh, vh, rq, rk, o, lse, pr, g, y, attn_alpha, sqk = ctx.saved_tensors
+        rt, impl = ctx.rt, ctx.impl
+        B, T, C, H, d, M = ctx.dims
+        cfg = rt.model.config
+        dt, td = rt.dt, ops.tdtype(rt.dt)
+        sh = rt.sh
+        dev = loc.device
+        c_q, c_a = 1.0 / cfg.base_scale, 0.05 / cfg.base_scale
+        dloc, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dx.contiguous(), loc, y, attn_alpha, c_a, None, None, None,
+                                                      False, False, True)
+        d_alpha = _param_grad_alpha(part_lam, attn_alpha, c_a)
+        dg = ops.gemm_nt(dy_lo, sh["x.out.Wt"], M, C, C, out_dtype=td)
+        g_wout = ops.gemm_tn(dy_lo, g, torch.empty((C, C), device=dev, dtype=torch.float32), M, C, C)
+        g_bout = _bias_grad(dy_lo, M, C) if ctx.has_b else None
+        dpr, _ = ops.swiglu_bwd(dt, dg, pr, None, 1.0, M, C)
+        do = ops.gemm_nt(dpr, sh["x.proj.Wt"], M, C, 2 * C, out_dtype=td)
+        g_wproj = ops.gemm_tn(dpr, o, torch.empty((2 * C, C), device=dev, dtype=torch.float32), M, 2 * C, C, perm=1)
+        g_bproj = _bias_grad(dpr, M, 2 * C, perm=1) if ctx.has_b else None
+        dqh, dkh, dvh = ops.attn_bwd(dt, impl, do, qh, kh, vh, o, lse, math.sqrt(d))
+        dq = torch.empty((M, C), device=dev, dtype=td)
+        dkv = torch.empty((M, 2 * C), device=dev, dtype=td)
+        part_sqk = ops.qknorm_bwd(dt, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q, dq, C, dkv, 2 * C, dkv[:, C:], 2 * C,
+                                  B, T, H, d)
+        d_sqk = _param_grad_scaled(part_sqk, sqk, c_q)
+        ops.gemm_nt(dq, sh["x.q.Wt"], M, C, C, out=dloc, accumulate=True)
+        dglo = ops.gemm_nt(dkv, sh["x.kv.Wt"], M, C, 2 * C, out_dtype=torch.float32)
+        g_wq = ops.gemm_tn(dq, loc_lo, torch.empty((C, C), device=dev, dtype=torch.float32), M, C, C)
+        g_wkv = ops.gemm_tn(dkv, glo_lo, torch.empty((2 * C, C), device=dev, dtype=torch.float32), M, 2 * C, C)
+        if ctx.has_b:
+            g_bq = _bias_grad(dq, M, C)
+            g_bkv = _bias_grad(dkv, M, 2 * C)
+            gbk, gbv = g_bkv[:C], g_bkv[C:]
+        else:
+            g_bq = gbk = gbv = None
+        return (dloc, dglo, None, None, d_alpha, d_sqk, g_wq, g_wkv[:C], g_wkv[C:], g_wproj, g_wout, g_bq, gbk, gbv,
+                g_bproj, g_bout)
+
+
+class _EmbedFn(torch.autograd.Function):
+    """Dual patch embedding + position embeddings (reference model.py:407-415) as im2col GEMMs."""
+
+    @staticmethod
+    def forward(ctx, img, rt, wl, bl, posl, wg, bg, posg):
+        cfg = rt.model.config
+        C = cfg.n_embd
+        Pl, Pg = cfg.local_patch_size, cfg.global_patch_size
+        B = img.shape[0]
+        T = rt.model.n_tokens
+        M = B * T
+        Kl, Kg = cfg.channels * Pl * Pl, cfg.channels * Pg * Pg
+        A_l, A_g = ops.im2col(rt.dt, img, Pl, Pg)
+        loc = ops.gemm_nt(A_l, rt.sh["pe_l"], M, C, Kl, bias=bl, rowadd=posl.reshape(T, C), rowadd_period=T)
+        glo = ops.gemm_nt(A_g, rt.sh["pe_g"], M, C, Kg, bias=bg, rowadd=posg.reshape(T, C), rowadd_period=T)
+        ctx.rt = rt
+        ctx.dims = (B, T, C, M, Kl, Kg)
+        ctx.shapes = (wl.shape, wg.shape, posl.shape)
+        ctx.save_for_backward(A_l, A_g)
+        return loc, glo
+
+    @staticmethod
+    def backward(ctx, dloc, dglo):
+        A_l, A_g = ctx.saved_tensors
+        rt = ctx.rt
+        B, T, C, M, Kl, Kg = ctx.dims
+        dev = A_l.device
+        out = []
+        for dy, A, K in ((dloc, A_l, Kl), (dglo, A_g, Kg)):
+            dy = dy.contiguous()
+            dy_lo = dy if rt.dt == F32 else ops.cast(dy, rt.dt)
+            gw = ops.gemm_tn(dy_lo, A, torch.empty((C, K), device=dev, dtype=torch.float32), M, C, K)
+            dpos = torch.empty((T, C), device=dev, dtype=torch.float32)
+            ops.colsum(dy, M, C, dpos, False, period=T)
+            db = torch.empty((C,), device=dev, dtype=torch.float32)
+            ops.colsum_big(dpos, T, C, db, False)
+            out.append((gw, db, dpos))
+        (gwl, dbl, dposl), (gwg, dbg, dposg) = out
+        wls, wgs, ps = ctx.shapes
+        return None, None, gwl.reshape(wls), dbl, dposl.reshape(ps), gwg.reshape(wgs), dbg, dposg.reshape(ps)
+
+
+class _HeadFn(torch.autograd.Function):
+    """mean-pool -> LayerNorm -> Linear -> * sz (reference model.py:455-456,466-468)."""
+
+    @staticmethod
+    def forward(ctx, x, rt, ln_w, ln_b, wh, bh, sz):
+        cfg = rt.model.config
+        C, ncls = cfg.n_embd, cfg.num_classes
+        T = rt.model.n_tokens
+        B = x.shape[0] // T
+        c_sz = cfg.sz_init_value / cfg.sz_init_scaling
+        pooled, ln, ln_lo, stats = ops.pool_ln_fwd(rt.dt, x, ln_w, ln_b, 1e-5, B, T, C)
+        raw = ops.gemm_nt(ln_lo, rt.sh["head.W"], B, ncls, C, bias=bh)
+        logits = ops.scale_cols(raw, sz, c_sz, B, ncls, torch.empty_like(raw))
+        ctx.rt = rt
+        ctx.dims = (B, T, C, ncls, c_sz)
+        ctx.save_for_backward(pooled, ln_lo, stats, raw, ln_w, sz)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        pooled, ln_lo, stats, raw, ln_w, sz = ctx.saved_tensors
+        rt = ctx.rt
+        B, T, C, ncls, c_sz = ctx.dims
+        dev = pooled.device
+        dt, td = rt.dt, ops.tdtype(rt.dt)
+        dlogits = dlogits.contiguous()
+        Kp = rt.sh["head.Wt"].shape[1]
+        d_sz = torch.empty_like(sz)
+        ops.colsum(dlogits, B, ncls, d_sz, False, b=raw, scale=c_sz)
+        draw = ops.scale_cols(dlogits, sz, c_sz, B, ncls, torch.empty((B, ncls), device=dev, dtype=torch.float32))
+        d_bh = torch.empty((ncls,), device=dev, dtype=torch.float32)
+        ops.colsum_big(draw, B, ncls, d_bh, False)
+        draw_lo = torch.zeros((B, Kp), device=dev, dtype=td)
+        ops.scale_cols(dlogits, sz, c_sz, B, ncls, draw_lo)
+        g_pad = ops.gemm_tn(draw_lo, ln_lo, torch.empty((Kp, C), device=dev, dtype=torch.float32), B, Kp, C)
+        dln = ops.gemm_nt(draw_lo, rt.sh["head.Wt"], B, C, Kp)
+        d_lnw = torch.empty_like(ln_w)
+        d_lnb = torch.empty_like(ln_w)
+        dx = ops.pool_ln_bwd(dln, pooled, ln_w, stats, d_lnw, d_lnb, False, B, T, C)
+        return dx, None, d_lnw, d_lnb, g_pad[:ncls], d_bh, d_sz
+
+
+# --------------------------------------------------------------------------------------------
+# Modules (parameter containers with the reference's names)
+# --------------------------------------------------------------------------------------------
+class Block(nn.Module):
+    def __init__(self, config: ViTConfig) -> None:
+        super().__init__()
+        self.config = config
+        C = config.n_embd
+        self.key = nn.Linear(C, C, bias=config.bias)
+        self.query = nn.Linear(C, C, bias=config.bias)
+        self.value = nn.Linear(C, C, bias=config.bias)
+        self.att_c_proj = nn.Linear(C, C, bias=config.bias)
+        self.skip_param = nn.Parameter(torch.ones(1))
+        self.c_fc = nn.Linear(C, 2 * 4 * C, bias=config.bias)
+        self.silu = nn.SiLU()
+        self.mlp_c_proj = nn.Linear(4 * C, C, bias=config.bias)
+        if config.use_nvit:
+            self.rmsnorm_att = RMSNorm(C)
+            self.rmsnorm_mlp = RMSNorm(C)
+            bs = config.base_scale
+            self.attn_alpha_init_value = torch.scalar_tensor(0.05, dtype=torch.float32)
+            self.attn_alpha_init_scaling = torch.scalar_tensor(bs, dtype=torch.float32)
+            self.attn_alpha = nn.Parameter(bs * torch.ones(C, dtype=torch.float32))
+            self.mlp_alpha_init_value = torch.scalar_tensor(0.05, dtype=torch.float32)
+            self.mlp_alpha_init_scaling = torch.scalar_tensor(bs, dtype=torch.float32)
+            self.mlp_alpha = nn.Parameter(bs * torch.ones(C, dtype=torch.float32))
+            self.sqk_init_value = torch.scalar_tensor(1.0, dtype=torch.float32)
+            self.sqk_init_scaling = torch.scalar_tensor(bs, dtype=torch.float32)
+            self.sqk = nn.Parameter(bs * torch.ones(C, dtype=torch.float32))
+            self.suv_init_value = torch.scalar_tensor(1.0, dtype=torch.float32)
+            self.suv_init_scaling = torch.scalar_tensor(1.0, dtype=torch.float32)
+            self.suv = nn.Parameter(torch.ones(2 * 4 * C, dtype=torch.float32))
+        self._owner = None  # set by ViT: (weakref to model, layer index)
+
+    def _args(self):
+        b = lambda l: l.bias
+        return (self.skip_param, self.attn_alpha, self.mlp_alpha, self.sqk, self.suv, self.query.weight,
+                self.key.weight, self.value.weight, self.att_c_proj.weight, self.c_fc.weight, self.mlp_c_proj.weight,
+                b(self.query), b(self.key), b(self.value), b(self.att_c_proj), b(self.c_fc), b(self.mlp_c_proj))
+
+    def _run(self, x: Tensor, x_lo: Tensor, with_skip: bool):
+        model, idx = self._owner
+        rt = model._rt
+        return _BlockFn.apply(x, x_lo, rt, idx, with_skip, model._attn_impl(), *self._args())
+
+    def forward(self, h: Tensor) -> Tensor:
+        """h [B,T,C] -> [B,T,C] (block output BEFORE norm_skip, like the reference)."""
+        model, _ = self._owner
+        B, T, C = h.shape
+        x, x_lo = model._enter(h.reshape(B * T, C))
+        out, _ = self._run(x, x_lo, False)
+        return out.reshape(B, T, C)
+
+
+class CrossAttentionBlock(nn.Module):
+    def __init__(self, config: ViTConfig) -> None:
+        super().__init__()
+        self.config = config
+        C = config.n_embd
+        if not config.use_nvit:
+            self.local_norm = RMSNorm(C)
+            self.global_norm = RMSNorm(C)
+        self.q_local = nn.Linear(C, C, bias=config.bias)
+        self.k_global = nn.Linear(C, C, bias=config.bias)
+        self.v_global = nn.Linear(C, C, bias=config.bias)
+        self.proj = nn.Linear(C, 2 * C, bias=config.bias)
+        self.silu = nn.SiLU()
+        self.out_proj = nn.Linear(C, C, bias=config.bias)
+        if config.use_nvit:
+            bs = config.base_scale
+            self.attn_alpha_init_value = torch.scalar_tensor(0.05, dtype=torch.float32)
+            self.attn_alpha_init_scaling = torch.scalar_tensor(bs, dtype=torch.float32)
+            self.attn_alpha = nn.Parameter(bs * torch.ones(C, dtype=torch.float32))
+            self.sqk_init_value = torch.scalar_tensor(1.0, dtype=torch.float32)
+            self.sqk_init_scaling = torch.scalar_tensor(bs, dtype=torch.float32)
+            self.sqk = nn.Parameter(bs * torch.ones(C, dtype=torch.float32))
+        self._owner = None
+
+    def _args(self):
+        b = lambda l: l.bias
+        return (self.attn_alpha, self.sqk, self.q_local.weight, self.k_global.weight, self.v_global.weight,
+                self.proj.weight, self.out_proj.weight, b(self.q_local), b(self.k_global), b(self.v_global),
+                b(self.proj), b(self.out_proj))
+
+    def _run(self, loc: Tensor, glo: Tensor):
+        model = self._owner
+        return _CrossFn.apply(loc, glo, model._rt, model._attn_impl(), *self._args())
+
+    def forward(self, local: Tensor, global_: Tensor) -> Tensor:
+        model = self._owner
+        B, T, C = local.shape
+        model._prepare(local.device)
+        x, _ = self._run(local.reshape(B * T, C).contiguous(), global_.reshape(B * T, C).contiguous())
+        return x.reshape(B, T, C)
+
+
+class ViT(nn.Module):
+    def __init__(self, config: ViTConfig):
+        super().__init__()
+        if not config.use_nvit:
+            raise NotImplementedError("only use_nvit=True is supported (the reference's non-nViT path crashes upstream)")
+        if config.use_kohonen:
+            raise NotImplementedError("the Kohonen head (BASELINE config C5) is not built yet")
+        if config.n_embd % config.n_head != 0 or config.n_embd % 64 != 0:
+            raise ValueError("n_embd must be a multiple of 64 and divisible by n_head")
+        if (config.n_embd // config.n_head) not in (32, 64):
+            raise ValueError("head dim must be 32 or 64")
+        self.config = config
+        self.step = 0
+        self.total_steps = 0
+        C = config.n_embd
+        Pl, Pg = config.local_patch_size, config.global_patch_size
+        self.local_patch_embed = nn.Conv2d(config.channels, C, kernel_size=Pl, stride=Pl)
+        self.global_patch_embed = nn.Sequential(
+            nn.ReflectionPad2d((Pg - Pl) // 2),
+            nn.Conv2d(config.channels, C, kernel_size=Pg, stride=Pl),
+        )
+        self.n_tokens = (config.image_size // Pl) ** 2
+        self.local_pos_embed = nn.Parameter(torch.zeros(1, self.n_tokens, C))
+        self.global_pos_embed = nn.Parameter(torch.zeros(1, self.n_tokens, C))
+        self.cross_attention = CrossAttentionBlock(config)
+        self.reconstruction_head = nn.Sequential(nn.Linear(C, Pl * Pl * config.channels), nn.Tanh())
+        self.transformer = nn.ModuleDict({
+            "drop": nn.Dropout(config.dropout),
+            "h": nn.ModuleList([Block(config) for _ in range(config.n_layer)]),
+        })
+        self.mlp_head = nn.Sequential(nn.LayerNorm(C), nn.Linear(C, config.num_classes))
+        self.sz = nn.Parameter(config.sz_init_scaling * torch.ones(config.num_classes, dtype=torch.float32))
+        self._init_parameters()
+        # runtime (not part of the state_dict)
+        self.precision = os.environ.get("NVIT_PRECISION", "bf16")
+        self.attn_impl = os.environ.get("NVIT_ATTN_IMPL", "auto")
+        object.__setattr__(self, "_rt", _Runtime(self))
+        object.__setattr__(self.cross_attention, "_owner", self)
+        for i, blk in enumerate(self.transformer.h):
+            object.__setattr__(blk, "_owner", (self, i))
+
+    # ---- init (reference model.py:354-367: Linear N(0,0.02), *c_proj N(0,0.02/sqrt(2L)), LN ones/zeros, sz const)
+    def _init_parameters(self) -> None:
+        L = self.config.n_layer
+        for name, mod in self.named_modules():
+            if isinstance(mod, nn.Linear):
+                std = 0.02 / math.sqrt(2 * L) if name.endswith("c_proj") else 0.02
+                nn.init.normal_(mod.weight, mean=0.0, std=std)
+                if mod.bias is not None:
+                    nn.init.zeros_(mod.bias)
+            elif isinstance(mod, nn.LayerNorm):
+                nn.init.ones_(mod.weight)
+                nn.init.zeros_(mod.bias)
+        with torch.no_grad():
+            self.sz.fill_(self.config.sz_init_value)
+
+    # ---- runtime helpers
+    def set_precision(self, precision: str) -> "ViT":
+        _dt_from_precision(precision)
+        self.precision = precision
+        return self
+
+    def _attn_impl(self) -> int:
+        if self.attn_impl == "auto":
+            return 1 if (self.precision == "bf16" and _mfma_attn_available()) else 0
+        return int(self.attn_impl)
+
+    def _prepare(self, device) -> None:
+        if device.type != "cuda":
+            raise RuntimeError("nvit_amd.ViT runs only on an MI355X (HIP device): the hot path has no CPU fallback. "
+                               "Use oracle/nvit_oracle.py for CPU reference numbers.")
+        self._rt.refresh(device, _dt_from_precision(self.precision))
+
+    def _enter(self, x: Tensor) -> Tuple[Tensor, Tensor]:
+        self._prepare(x.device)
+        x = x.contiguous().float()
+        return x, (x if self._rt.dt == F32 else ops.cast(x, self._rt.dt))
+
+    # ---- reference API
+    def configure_optimizers(self, weight_decay: float, learning_rate: float, betas: Tuple[float, float],
+                             device_type: str) -> torch.optim.AdamW:
+        """Same parameter groups as reference model.py:369-385 (nViT branch); torch's AdamW (out of scope, F1)."""
+        pd = {n: p for n, p in self.named_parameters() if p.requires_grad}
+        groups = [
+            {"params": [p for n, p in pd.items() if "sz" not in n and p.dim() >= 2], "weight_decay": weight_decay},
+            {"params": [p for n, p in pd.items() if "sz" not in n and p.dim() < 2], "weight_decay": 0.0},
+            {"params": [self.sz], "weight_decay": 0.0},
+        ]
+        return torch.optim.AdamW(groups, lr=learning_rate, betas=betas, fused=(device_type == "cuda"))
+
+    def estimate_mfu(self, fwdbwd_per_iter: int, dt: float) -> Tuple[float, float]:
+        """Reference formula (model.py:387-401): 6N + 12LHQT per token against the A100 constant 312e12."""
+        cfg = self.config
+        N = self.num_params
+        L, H, Q = cfg.n_layer, cfg.n_head, cfg.n_embd // cfg.n_head
+        T = self.n_tokens
+        flops = (6 * N + 12 * L * H * Q * T) * T * fwdbwd_per_iter / dt
+        return flops / 312e12, flops
+
+    @property
+    def num_params(self) -> int:
+        return sum(p.numel() for p in self.parameters())
+
+    def get_kohonen_lr(self, step: int) -> float:
+        cfg = self.config
+        if not cfg.kohonen_scheduler_enabled:
+            return cfg.kohonen_alpha
+        w, dcy = cfg.kohonen_scheduler_warmup_steps, cfg.kohonen_scheduler_decay_steps
+        lo, hi = cfg.kohonen_scheduler_min_lr, cfg.kohonen_alpha
+        if step < w:
+            return lo + (hi - lo) * (step / w)
+        if step > dcy:
+            return lo
+        return lo + 0.5 * (1.0 + math.cos(math.pi * (step - w) / (dcy - w))) * (hi - lo)
+
+    def forward(self, img: Tensor) -> Tuple[Tensor, Dict[str, Tensor]]:
+        if self.training:
+            self.step += 1
+        self._prepare(img.device)
+        rt = self._rt
+        cfg = self.config
+        B = img.shape[0]
+        T, C = self.n_tokens, cfg.n_embd
+        img = img.contiguous().float()
+        loc, glo = _EmbedFn.apply(img, rt, self.local_patch_embed.weight, self.local_patch_embed.bias,
+                                  self.local_pos_embed, self.global_patch_embed[1].weight,
+                                  self.global_patch_embed[1].bias, self.global_pos_embed)
+        x, x_lo = self.cross_attention._run(loc, glo)
+        for blk in self.transformer.h:
+            x, x_lo = blk._run(x, x_lo, True)
+        logits = _HeadFn.apply(x, rt, self.mlp_head[0].weight, self.mlp_head[0].bias, self.mlp_head[1].weight,
+                               self.mlp_head[1].bias, self.sz)
+        aux: Dict[str, Tensor] = {}
+        with torch.no_grad():
+            Kl = cfg.channels * cfg.local_patch_size ** 2
+            raw = ops.gemm_nt(x_lo, rt.sh["rec.W"], B * T, Kl, C, bias=self.reconstruction_head[0].bias)
+            aux["reconstruction"] = ops.recon_loss(raw, img, cfg.local_patch_size)
+        return logits, aux
+
+
+_MFMA_ATTN = None
+
+
+def _mfma_attn_available() -> bool:
+    global _MFMA_ATTN
+    if _MFMA_ATTN is None:
+        _MFMA_ATTN = os.environ.get("NVIT_MFMA_ATTN", "0") == "1"
+    return _MFMA_ATTN

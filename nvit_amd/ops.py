@@ -1,0 +1,340 @@
+"""Thin Python wrappers over the C ABI (include/nvit_hip.h).
+
+PyTorch is used here only as plumbing: device memory (caching allocator), the current HIP
+stream, and dtype bookkeeping.  Every function enqueues hand-written HIP kernels on
+`torch.cuda.current_stream()`; nothing falls back to torch operators.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, check
+
+Tensor = torch.Tensor
+
+
+def tdtype(dt: int) -> torch.dtype:
+    return torch.float32 if dt == F32 else torch.bfloat16
+
+
+def dt_of(t: Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t: Optional[Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk_dev(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("nvit_amd ops need device tensors: the nViT hot path has no CPU fallback")
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def bk_of(dt: int) -> int:
+    return 32 if dt == F32 else 64
+
+
+# ----------------------------------------------------------------------------- GEMMs
+def gemm_nt(A: Tensor, B: Tensor, M: int, N: int, K: int, out: Optional[Tensor] = None,
+            out_dtype: torch.dtype = torch.float32, bias: Optional[Tensor] = None,
+            colscale: Optional[Tensor] = None, rowadd: Optional[Tensor] = None, rowadd_period: int = 0,
+            accumulate: bool = False, lda: Optional[int] = None, ldb: Optional[int] = None,
+            ldc: Optional[int] = None) -> Tensor:
+    """out[M,N] = A[M,K] @ B[N,K]^T (+epilogue). A,B same dtype (fp32 or bf16)."""
+    _chk_dev(A, B)
+    dt = dt_of(A)
+    assert dt_of(B) == dt
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    if out is None:
+        out = torch.empty((M, N), device=A.device, dtype=out_dtype)
+    ldc = out.stride(0) if ldc is None else ldc
+    check(_lib.load().nvit_gemm_nt(dt, _p(A), lda, _p(B), ldb, _p(out), ldc, dt_of(out), M, N, K, _p(bias),
+                                   _p(colscale), _p(rowadd), rowadd_period, int(accumulate), _s()), "nvit_gemm_nt")
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes: int, device) -> Tensor:
+    key = (device, torch.cuda.current_stream().cuda_stream)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes // 4 + 1, 1 << 20), device=device, dtype=torch.float32)
+        _ws_cache[key] = ws
+    return ws
+
+
+def tn_splits(Mred: int, N: int, K: int, dt: int) -> int:
+    tiles = math.ceil(N / 128) * math.ceil(K / 128)
+    rb = bk_of(dt)
+    want = max(1, math.ceil(1024 / tiles))
+    return max(1, min(want, math.ceil(Mred / (4 * rb)), 64))
+
+
+def gemm_tn(A: Tensor, B: Tensor, G: Tensor, Mred: int, N: int, K: int, perm: int = 0, accumulate: bool = False,
+            lda: Optional[int] = None, ldb: Optional[int] = None, ldg: Optional[int] = None) -> Tensor:
+    """G[N,K] (+)= A[Mred,N]^T @ B[Mred,K]; G fp32."""
+    _chk_dev(A, B, G)
+    dt = dt_of(A)
+    assert dt_of(B) == dt and G.dtype == torch.float32
+    lda = A.stride(0) if lda is None else lda
+    ldb = B.stride(0) if ldb is None else ldb
+    ldg = G.stride(0) if ldg is None else ldg
+    splits = tn_splits(Mred, N, K, dt)
+    nbytes = splits * N * K * 4
+    ws = _workspace(nbytes, A.device)
+    check(_lib.load().nvit_gemm_tn(dt, _p(A), lda, _p(B), ldb, _p(G), ldg, Mred, N, K, splits, _p(ws),
+                                   ws.numel() * 4, perm, int(accumulate), _s()), "nvit_gemm_tn")
+    return G
+
+
+# ----------------------------------------------------------------------------- row ops
+PART_BLOCKS = 1024
+
+
+def lerp_fwd(dt: int, h: Tensor, y: Tensor, alpha: Tensor, c_a: float, skip_x: Optional[Tensor] = None,
+             skip: Optional[Tensor] = None, want_lo: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    M, Cc = h.shape
+    out = torch.empty_like(h)
+    out_lo = torch.empty((M, Cc), device=h.device, dtype=tdtype(dt)) if want_lo else None
+    check(_lib.load().nvit_lerp_fwd(dt, _p(h), _p(y), dt_of(y), _p(alpha), c_a, _p(skip_x), _p(skip), _p(out),
+                                    _p(out_lo), M, Cc, _s()), "nvit_lerp_fwd")
+    return out, out_lo
+
+
+def lerp_bwd(dt: int, dout: Tensor, h: Tensor, y: Tensor, alpha: Tensor, c_a: float, skip_x: Optional[Tensor],
+             skip: Optional[Tensor], dh: Optional[Tensor], accum_dh: bool, want_dy_f32: bool, want_dy_lo: bool):
+    """-> dh, dy_f32|None, dy_lo|None, dskip_x|None, part_dlam [nblk,C], part_dskip|None"""
+    M, Cc = h.shape
+    dev = h.device
+    nblk = min(PART_BLOCKS, math.ceil(M / 4))
+    if dh is None:
+        dh = torch.empty_like(h)
+        accum_dh = False
+    dy = torch.empty_like(h) if want_dy_f32 else None
+    dy_lo = torch.empty((M, Cc), device=dev, dtype=tdtype(dt)) if want_dy_lo else None
+    dskip_x = torch.empty_like(h) if skip_x is not None else None
+    part = torch.empty((nblk, Cc), device=dev, dtype=torch.float32)
+    pskip = torch.empty((nblk,), device=dev, dtype=torch.float32) if skip_x is not None else None
+    check(_lib.load().nvit_lerp_bwd(dt, _p(dout), _p(h), _p(y), dt_of(y), _p(alpha), c_a, _p(skip_x), _p(skip),
+                                    _p(dh), int(accum_dh), _p(dy), _p(dy_lo), _p(dskip_x), _p(part), _p(pskip),
+                                    nblk, M, Cc, _s()), "nvit_lerp_bwd")
+    return dh, dy, dy_lo, dskip_x, part, pskip
+
+
+def qknorm_fwd(dt: int, q: Tensor, ldq: int, k: Tensor, ldk: int, v: Tensor, ldv: int, sqk: Tensor, c_q: float,
+               B: int, T: int, H: int, d: int):
+    dev = sqk.device
+    td = tdtype(dt)
+    qh = torch.empty((B, H, T, d), device=dev, dtype=td)
+    kh = torch.empty_like(qh)
+    vh = torch.empty_like(qh)
+    rq = torch.empty((B * T, H), device=dev, dtype=torch.float32)
+    rk = torch.empty_like(rq)
+    check(_lib.load().nvit_qknorm_fwd(dt, _p(q), ldq, _p(k), ldk, _p(v), ldv, _p(sqk), c_q, _p(qh), _p(kh), _p(vh),
+                                      _p(rq), _p(rk), B, T, H, d, _s()), "nvit_qknorm_fwd")
+    return qh, kh, vh, rq, rk
+
+
+def qknorm_bwd(dt: int, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q: float, dq: Tensor, ldq: int, dk: Tensor, ldk: int,
+               dv: Tensor, ldv: int, B: int, T: int, H: int, d: int) -> Tensor:
+    nblk = min(PART_BLOCKS, math.ceil(B * T / 4))
+    part = torch.empty((nblk, H * d), device=sqk.device, dtype=torch.float32)
+    check(_lib.load().nvit_qknorm_bwd(dt, _p(dqh), _p(dkh), _p(dvh), _p(qh), _p(kh), _p(rq), _p(rk), _p(sqk), c_q,
+                                      _p(dq), ldq, _p(dk), ldk, _p(dv), ldv, _p(part), nblk, B, T, H, d, _s()),
+          "nvit_qknorm_bwd")
+    return part
+
+
+def swiglu_fwd(dt: int, uv: Tensor, suv: Optional[Tensor], gscale: float, M: int, F: int) -> Tensor:
+    x = torch.empty((M, F), device=uv.device, dtype=tdtype(dt))
+    check(_lib.load().nvit_swiglu_fwd(dt, _p(uv), _p(suv), gscale, _p(x), M, F, _s()), "nvit_swiglu_fwd")
+    return x
+
+
+def swiglu_bwd(dt: int, dx: Tensor, uv: Tensor, suv: Optional[Tensor], gscale: float, M: int, F: int):
+    duv = torch.empty((M, 2 * F), device=uv.device, dtype=tdtype(dt))
+    colblocks = math.ceil(F / 1024)
+    rowblocks = max(1, min(M, math.ceil(2048 / colblocks)))
+    rpb = math.ceil(M / rowblocks)
+    nrb = math.ceil(M / rpb)
+    part = torch.empty((nrb, 2 * F), device=uv.device, dtype=torch.float32) if suv is not None else None
+    check(_lib.load().nvit_swiglu_bwd(dt, _p(dx), _p(uv), _p(suv), gscale, _p(duv), _p(part), rpb, M, F, _s()),
+          "nvit_swiglu_bwd")
+    return duv, part
+
+
+def colsum_reduce(part: Tensor, out: Tensor, accumulate: bool, kind: int = 0, ref: Optional[Tensor] = None,
+                  scale: float = 1.0) -> None:
+    nblk, N = part.shape if part.dim() == 2 else (part.shape[0], 1)
+    check(_lib.load().nvit_colsum_reduce(_p(part), nblk, N, _p(out), int(accumulate), kind, _p(ref), scale, _s()),
+          "nvit_colsum_reduce")
+
+
+def colsum(a: Tensor, R: int, N: int, out: Tensor, accumulate: bool, b: Optional[Tensor] = None, period: int = 0,
+           scale: float = 1.0, lda: Optional[int] = None, ldb: Optional[int] = None) -> None:
+    lda = a.stride(0) if lda is None else lda
+    ldb = (b.stride(0) if ldb is None else ldb) if b is not None else 0
+    check(_lib.load().nvit_colsum(_p(a), dt_of(a), lda, _p(b), dt_of(b) if b is not None else F32, ldb, R, N,
+                                  period, _p(out), int(accumulate), scale, _s()), "nvit_colsum")
+
+
+def colsum_big(a: Tensor, R: int, N: int, out: Tensor, accumulate: bool, lda: Optional[int] = None) -> None:
+    """column sums over many rows: fold rows modulo 512 first, then reduce the 512 partial rows."""
+    if R <= 1024:
+        colsum(a, R, N, out, accumulate, lda=lda)
+        return
+    part = torch.empty((512, N), device=a.device, dtype=torch.float32)
+    colsum(a, R, N, part, False, period=512, lda=lda)
+    colsum(part, 512, N, out, accumulate)
+
+
+def cast(src: Tensor, dt: int) -> Tensor:
+    dst = torch.empty(src.shape, device=src.device, dtype=tdtype(dt))
+    check(_lib.load().nvit_cast(_p(src), _p(dst), dt, src.numel(), _s()), "nvit_cast")
+    return dst
+
+
+def scale_cols(a: Tensor, s: Tensor, c: float, R: int, N: int, out: Tensor, lda: Optional[int] = None,
+               ldo: Optional[int] = None) -> Tensor:
+    lda = a.stride(0) if lda is None else lda
+    ldo = out.stride(0) if ldo is None else ldo
+    check(_lib.load().nvit_scale_cols(_p(a), lda, _p(s), c, _p(out), dt_of(out), ldo, R, N, _s()), "nvit_scale_cols")
+    return out
+
+
+# ----------------------------------------------------------------------------- attention
+def attn_fwd(dt: int, impl: int, qh: Tensor, kh: Tensor, vh: Tensor, scale: float):
+    B, H, Tq, d = qh.shape
+    Tk = kh.shape[2]
+    o = torch.empty((B * Tq, H * d), device=qh.device, dtype=tdtype(dt))
+    lse = torch.empty((B, H, Tq), device=qh.device, dtype=torch.float32)
+    check(_lib.load().nvit_attn_fwd(dt, impl, _p(qh), _p(kh), _p(vh), scale, _p(o), _p(lse), B, H, Tq, Tk, d, _s()),
+          "nvit_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(dt: int, impl: int, dout: Tensor, qh: Tensor, kh: Tensor, vh: Tensor, o: Tensor, lse: Tensor,
+             scale: float):
+    B, H, Tq, d = qh.shape
+    Tk = kh.shape[2]
+    dqh = torch.empty_like(qh)
+    dkh = torch.empty_like(kh)
+    dvh = torch.empty_like(vh)
+    delta = torch.empty((B, H, Tq), device=qh.device, dtype=torch.float32)
+    check(_lib.load().nvit_attn_bwd(dt, impl, _p(dout), _p(qh), _p(kh), _p(vh), _p(o), _p(lse), scale, _p(dqh),
+                                    _p(dkh), _p(dvh), _p(delta), B, H, Tq, Tk, d, _s()), "nvit_attn_bwd")
+    return dqh, dkh, dvh
+
+
+# ----------------------------------------------------------------------------- embed / head
+def im2col(dt: int, img: Tensor, Pl: int, Pg: int):
+    B, ch, S, _ = img.shape
+    T = (S // Pl) ** 2
+    A_l = torch.empty((B * T, ch * Pl * Pl), device=img.device, dtype=tdtype(dt))
+    A_g = torch.empty((B * T, ch * Pg * Pg), device=img.device, dtype=tdtype(dt))
+    check(_lib.load().nvit_im2col(dt, _p(img), _p(A_l), _p(A_g), B, ch, S, Pl, Pg, _s()), "nvit_im2col")
+    return A_l, A_g
+
+
+def pool_ln_fwd(dt: int, x: Tensor, w: Tensor, b: Tensor, eps: float, B: int, T: int, Cc: int):
+    dev = x.device
+    nchunk = max(1, min(T, math.ceil(1024 / B)))
+    pooled = torch.empty((B, Cc), device=dev, dtype=torch.float32)
+    ln = torch.empty_like(pooled)
+    ln_lo = torch.empty((B, Cc), device=dev, dtype=tdtype(dt))
+    stats = torch.empty((B, 2), device=dev, dtype=torch.float32)
+    ws = torch.empty((B, nchunk, Cc), device=dev, dtype=torch.float32)
+    check(_lib.load().nvit_pool_ln_fwd(dt, _p(x), _p(w), _p(b), eps, _p(pooled), _p(ln), _p(ln_lo), _p(stats), _p(ws),
+                                       nchunk, B, T, Cc, _s()), "nvit_pool_ln_fwd")
+    return pooled, ln, ln_lo, stats
+
+
+def pool_ln_bwd(dln: Tensor, pooled: Tensor, w: Tensor, stats: Tensor, dw: Tensor, db: Tensor, accumulate: bool,
+                B: int, T: int, Cc: int) -> Tensor:
+    dx = torch.empty((B * T, Cc), device=dln.device, dtype=torch.float32)
+    check(_lib.load().nvit_pool_ln_bwd(_p(dln), _p(pooled), _p(w), _p(stats), _p(dx), _p(dw), _p(db),
+                                       int(accumulate), B, T, Cc, _s()), "nvit_pool_ln_bwd")
+    return dx
+
+
+def recon_loss(raw: Tensor, img: Tensor, P: int) -> Tensor:
+    B, ch, S, _ = img.shape
+    nblk = 1024
+    part = torch.empty((nblk,), device=img.device, dtype=torch.float32)
+    loss = torch.empty((1,), device=img.device, dtype=torch.float32)
+    check(_lib.load().nvit_recon_loss(_p(raw), _p(img), _p(part), nblk, _p(loss), B, ch, S, P, _s()),
+          "nvit_recon_loss")
+    return loss.reshape(())
+
+
+# ----------------------------------------------------------------------------- weights
+def renorm_table(mats, device) -> Tuple[Tensor, int]:
+    """mats: list of (tensor fp32 [rows, cols] contiguous, dim). -> device table, total_items"""
+    rows_, first = [], 0
+    for w, dim in mats:
+        assert w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2
+        r, c = w.shape
+        if dim == 0 and r > 1152:
+            raise RuntimeError(f"renorm: column-normalised matrix with {r} rows exceeds the LDS slab (1152)")
+        items = math.ceil(r / _lib.RENORM_ROWS_PER_ITEM) if dim == 1 else math.ceil(c / _lib.RENORM_COLS_PER_ITEM)
+        rows_.append([w.data_ptr(), r, c, dim, first])
+        first += items
+    return torch.tensor(rows_, dtype=torch.int64).to(device), first
+
+
+def renorm_weights(table: Tensor, total_items: int) -> None:
+    check(_lib.load().nvit_renorm_weights(_p(table), table.shape[0], total_items, _s()), "nvit_renorm_weights")
+
+
+def shadow_table(entries, device) -> Tuple[Tensor, int]:
+    """entries: list of (src fp32 2-D view, dst|None, dst_ld, dst_cols, dstT|None, dstT_ld, dstT_cols, perm)."""
+    rows_, first = [], 0
+    for src, dst, dst_ld, dst_cols, dstT, dstT_ld, dstT_cols, perm in entries:
+        assert src.dtype == torch.float32 and src.is_contiguous()
+        r, c = src.shape[0], src.numel() // src.shape[0]
+        tiles_c = math.ceil(max(c, dst_cols if dst is not None else 0) / 64)
+        tiles_r = math.ceil(max(r, dstT_cols if dstT is not None else 0) / 64)
+        rows_.append([src.data_ptr(), r, c, dst.data_ptr() if dst is not None else 0, dst_ld, dst_cols,
+                      dstT.data_ptr() if dstT is not None else 0, dstT_ld, dstT_cols, perm, first, tiles_c])
+        first += tiles_c * tiles_r
+    return torch.tensor(rows_, dtype=torch.int64).to(device), first
+
+
+def shadow_weights(table: Tensor, total_items: int, dt: int) -> None:
+    check(_lib.load().nvit_shadow_weights(_p(table), table.shape[0], total_items, dt, _s()), "nvit_shadow_weights")
+
+
+# ----------------------------------------------------------------------------- profiling
+def prof_enable(on: bool) -> None:
+    _lib.load().nvit_prof_enable(int(on))
+
+
+def prof_collect():
+    n = len(_lib.KID_NAMES)
+    ms = (C.c_double * n)()
+    fl = (C.c_double * n)()
+    by = (C.c_double * n)()
+    ln = (C.c_int64 * n)()
+    check(_lib.load().nvit_prof_collect(ms, fl, by, ln), "nvit_prof_collect")
+    return {_lib.KID_NAMES[i]: {"ms": ms[i], "flops": fl[i], "bytes": by[i], "launches": ln[i]} for i in range(n)}

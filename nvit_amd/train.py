@@ -1,0 +1,65 @@
+"""Post-step weight re-normalisation and the reference's train-step order.
+
+`normalize_matrices(model)` replaces Trainer.normalize_matrices
+(/root/reference/nvit/train.py:461-480): same six matrices per block, same axes, fp32 in
+place — but ONE persistent HIP launch instead of ~30 torch kernels per block.
+
+`train_step` reproduces the call sequence of the reference hot loop
+(train.py:898-946,989-990): forward -> cross_entropy -> backward -> clip_grad_norm_(1.0) ->
+AdamW.step -> zero_grad(set_to_none) -> normalize_matrices.  Cross-entropy, clipping and AdamW
+stay torch operators on the ROCm device (out of scope).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+_RENORM_ROWS = ("query", "key", "value", "c_fc")     # dim=1
+_RENORM_COLS = ("att_c_proj", "mlp_c_proj")          # dim=0
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def normalize_matrices(model) -> None:
+    m = _unwrap(model)
+    if not m.config.use_nvit:
+        return
+    mats = []
+    for blk in m.transformer.h:
+        for n in ("query", "key", "value"):
+            mats.append((getattr(blk, n).weight.data, 1))
+        mats.append((blk.att_c_proj.weight.data, 0))
+        mats.append((blk.c_fc.weight.data, 1))
+        mats.append((blk.mlp_c_proj.weight.data, 0))
+    dev = mats[0][0].device
+    if dev.type != "cuda":
+        raise RuntimeError("normalize_matrices: parameters must live on the HIP device (no CPU fallback)")
+    key = tuple(w.data_ptr() for w, _ in mats)
+    cache = getattr(m, "_renorm_cache", None)
+    if cache is None or cache[0] != key:
+        table, items = ops.renorm_table(mats, dev)
+        cache = (key, table, items)
+        object.__setattr__(m, "_renorm_cache", cache)
+    ops.renorm_weights(cache[1], cache[2])
+
+
+def train_step(model, optimizer, X: torch.Tensor, y: torch.Tensor, grad_clip: float = 1.0,
+               sync_grads=None):
+    """One optimizer step in the reference's order; returns (logits, loss, aux, grad_norm)."""
+    logits, aux = model(X)
+    loss = F.cross_entropy(logits, y)
+    loss.backward()
+    if sync_grads is not None:
+        sync_grads()
+    params = [p for p in _unwrap(model).parameters() if p.grad is not None]
+    gnorm = torch.nn.utils.clip_grad_norm_(params, grad_clip) if grad_clip != 0.0 else None
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    normalize_matrices(model)
+    return logits.detach(), loss.detach(), aux, gnorm

@@ -1,0 +1,139 @@
+"""GPU parity tests, whole path: the HIP-backed model against the CPU oracle on the same
+formula weights and inputs, and against the committed reference golden vectors.
+
+fp32 mode: tolerance 1e-5 on logits (BASELINE.json north_star), tight relative tolerances on
+gradients.  bf16 mode: 1e-3 target on logits is REPORTED (the reference's own bf16 autocast
+deviates 3.3e-3..7.2e-3 from its fp32); the asserted bound is 5e-3."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from nvit_amd.config import named_config
+from nvit_amd.weights import formula_state_dict, synthetic_batch
+from oracle import nvit_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def build(cfg, precision, renormed):
+    from nvit_amd.model import ViT
+    from nvit_amd.train import normalize_matrices
+    m = ViT(cfg)
+    m.load_state_dict(formula_state_dict(cfg))
+    m = m.to("cuda:0").set_precision(precision)
+    if renormed:
+        normalize_matrices(m)
+    return m
+
+
+def oracle_run(cfg, X, y, renormed, lowp=None):
+    p = O.make_params(formula_state_dict(cfg))
+    if renormed:
+        O.renorm_(p, cfg)
+    logits, loss, recon = O.loss_and_grads(p, cfg, X, y, lowp)
+    return p, logits, loss, recon
+
+
+CASES = [("micro", 8), ("mini", 4), ("tiny", 32)]
+
+
+@pytest.mark.parametrize("name,batch", CASES)
+@pytest.mark.parametrize("renormed", [False, True])
+def test_fp32_forward_backward_vs_oracle(name, batch, renormed):
+    torch.set_num_threads(8)
+    cfg = named_config(name)
+    X, y = synthetic_batch(cfg, batch)
+    p, logits_ref, loss_ref, recon_ref = oracle_run(cfg, X, y, renormed)
+    m = build(cfg, "fp32", renormed).train()
+    logits, aux = m(X.cuda())
+    loss = torch.nn.functional.cross_entropy(logits, y.cuda())
+    loss.backward()
+    err = (logits.detach().cpu() - logits_ref).abs().max().item()
+    print(f"[fp32 {name} renorm={renormed}] max|dlogit|={err:.3e} loss {loss.item():.6f} vs {loss_ref.item():.6f}")
+    assert err < 1e-5
+    assert abs(loss.item() - loss_ref.item()) < 1e-5
+    assert abs(aux["reconstruction"].item() - recon_ref.item()) < 1e-5
+    have = {n for n, q in m.named_parameters() if q.grad is not None}
+    want = {n for n, t in p.items() if t.grad is not None}
+    assert have == want
+    worst = 0.0
+    for n, q in m.named_parameters():
+        if q.grad is None:
+            continue
+        ref = p[n].grad
+        e = (q.grad.cpu() - ref).abs().max().item()
+        s = ref.abs().max().item()
+        worst = max(worst, e / (s + 1e-12))
+        assert e <= 2e-4 * s + 1e-8, (n, e, s)
+    print(f"   worst relative grad error {worst:.3e}")
+
+
+@pytest.mark.parametrize("name,batch", CASES)
+def test_fp32_matches_reference_golden_and_one_step(name, batch):
+    """Directly against numbers recorded from the real reference (tests/golden), incl. one full
+    train step (clip + AdamW + renorm) and the step-1 logits."""
+    from nvit_amd.train import train_step
+    g = np.load(os.path.join(GOLD, f"{name}_b{batch}_init.npz"))
+    cfg = named_config(name)
+    X, y = synthetic_batch(cfg, batch)
+    m = build(cfg, "fp32", False).train()
+    opt = m.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")
+    logits, loss, aux, gnorm = train_step(m, opt, X.cuda(), y.cuda(), 1.0)
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 2e-5
+    assert abs(loss.item() - float(g["loss"])) < 2e-5
+    assert abs(gnorm.item() - float(g["gnorm"])) < 2e-4 * float(g["gnorm"])
+    with torch.no_grad():
+        logits1, aux1 = m(X.cuda())
+    e1 = np.abs(logits1.cpu().numpy() - g["logits1"]).max()
+    print(f"[golden {name}] step-1 max|dlogit| = {e1:.3e}")
+    assert e1 < 1e-4
+    q0 = m.transformer.h[0].query.weight.detach().reshape(-1)[:8].cpu().numpy()
+    assert np.abs(q0 - g["q0_head1"]).max() < 2e-6
+    for blk in m.transformer.h:
+        for lin, dim in ((blk.query, 1), (blk.key, 1), (blk.value, 1), (blk.c_fc, 1), (blk.att_c_proj, 0),
+                         (blk.mlp_c_proj, 0)):
+            assert (lin.weight.detach().norm(dim=dim) - 1).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("name,batch", CASES)
+def test_bf16_forward_backward_vs_oracle(name, batch):
+    cfg = named_config(name)
+    X, y = synthetic_batch(cfg, batch)
+    p, logits_ref, loss_ref, _ = oracle_run(cfg, X, y, True)
+    pe, logits_emu, _, _ = oracle_run(cfg, X, y, True, lowp=O.bf16_round)
+    m = build(cfg, "bf16", True).train()
+    logits, aux = m(X.cuda())
+    loss = torch.nn.functional.cross_entropy(logits, y.cuda())
+    loss.backward()
+    err = (logits.detach().cpu() - logits_ref).abs().max().item()
+    err_emu = (logits.detach().cpu() - logits_emu).abs().max().item()
+    lmax = logits_ref.abs().max().item()
+    print(f"[bf16 {name}] max|dlogit| vs fp32 oracle {err:.3e} (|logit|max {lmax:.3f}, rel {err / lmax:.3e}); "
+          f"vs bf16-operand oracle {err_emu:.3e}")
+    assert err < 5e-3
+    # gradients: cosine similarity per parameter against the fp32 oracle
+    worst = 1.0
+    for n, q in m.named_parameters():
+        if q.grad is None:
+            continue
+        a, b = q.grad.cpu().flatten().double(), p[n].grad.flatten().double()
+        if b.norm() < 1e-12:
+            continue
+        cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        worst = min(worst, cos)
+        assert cos > 0.98, (n, cos)
+        assert abs(a.norm() / b.norm() - 1) < 0.1, (n, a.norm().item(), b.norm().item())
+    print(f"   worst grad cosine {worst:.5f}")
+
+
+def test_state_dict_keys_and_no_cpu_fallback():
+    from nvit_amd.model import ViT
+    cfg = named_config("micro")
+    m = ViT(cfg)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 32))
