@@ -181,6 +181,12 @@ def _bias_grad(dy_lo: Tensor, M: int, N: int, perm: int = 0) -> Tensor:
     return g
 
 
+def _lo(rt: _Runtime, x: Tensor, x_lo: Tensor) -> Tensor:
+    """MFMA-operand copy of the residual stream: the bf16 twin written by the producing kernel, or
+    (fp32 mode) the fp32 tensor itself, detached."""
+    return x.detach() if rt.dt == F32 else x_lo
+
+
 class _BlockFn(torch.autograd.Function):
     """One nGPT block (+ norm_skip): reference Block.forward (model.py:92-169) followed by
     Block.norm_skip (model.py:84-87) as called at model.py:450-452."""
@@ -216,7 +222,7 @@ class _BlockFn(torch.autograd.Function):
         else:
             xn, xn_lo = ops.lerp_fwd(dt, h1, y2, mlp_alpha, c_a, want_lo=(dt != F32))
         if dt == F32:
-            xn_lo = xn
+            xn_lo = xn.new_empty(0)  # placeholder: callers alias x itself in fp32 mode (see _lo())
         ctx.rt, ctx.idx, ctx.with_skip, ctx.impl, ctx.has_b = rt, idx, with_skip, impl, has_b
         ctx.dims = (B, T, C, H, d, M)
         ctx.save_for_backward(x, x_lo, qh, kh, vh, rq, rk, o, lse, y, h1, h1_lo, uv, xm, y2, skip_param, attn_alpha,
@@ -317,7 +323,7 @@ class _CrossFn(torch.autograd.Function):
         y = ops.gemm_nt(g, sh["x.out.W"], M, C, C, out_dtype=torch.float32, bias=sh.get("x.out.b"))
         x, x_lo = ops.lerp_fwd(dt, loc, y, attn_alpha, c_a, want_lo=(dt != F32))
         if dt == F32:
-            x_lo = x
+            x_lo = x.new_empty(0)
         ctx.rt, ctx.impl, ctx.has_b = rt, impl, has_b
         ctx.dims = (B, T, C, H, d, M)
         ctx.save_for_backward(loc, glo, loc_lo, glo_lo, qh, kh, vh, rq, rk, o, lse, pr, g, y, attn_alpha, sqk)
@@ -491,7 +497,8 @@ class Block(nn.Module):
     def _run(self, x: Tensor, x_lo: Tensor, with_skip: bool):
         model, idx = self._owner
         rt = model._rt
-        return _BlockFn.apply(x, x_lo, rt, idx, with_skip, model._attn_impl(), *self._args())
+        xn, xn_lo = _BlockFn.apply(x, x_lo, rt, idx, with_skip, model._attn_impl(), *self._args())
+        return xn, _lo(rt, xn, xn_lo)
 
     def forward(self, h: Tensor) -> Tensor:
         """h [B,T,C] -> [B,T,C] (block output BEFORE norm_skip, like the reference)."""
@@ -534,7 +541,8 @@ class CrossAttentionBlock(nn.Module):
 
     def _run(self, loc: Tensor, glo: Tensor):
         model = self._owner
-        return _CrossFn.apply(loc, glo, model._rt, model._attn_impl(), *self._args())
+        x, x_lo = _CrossFn.apply(loc, glo, model._rt, model._attn_impl(), *self._args())
+        return x, _lo(model._rt, x, x_lo)
 
     def forward(self, local: Tensor, global_: Tensor) -> Tensor:
         model = self._owner
