@@ -1,11 +1,477 @@
-// impl 1: MFMA flash attention (bf16).  Placeholder until the kernels land: fails loudly.
+// impl 1: MFMA flash attention for gfx950 (bf16 operands, fp32 softmax/accumulate), head dim 64.
+// Non-causal, unmasked, arbitrary (ragged) sequence lengths.
+//
+// Orientation (everything is computed "key-major" so that per-query softmax statistics are
+// per-LANE scalars and the probability tile never leaves registers):
+//   S^T[key][q] = K Q^T      MFMA-A = K rows (ds_read_b128 from the LDS K tile),
+//                            MFMA-B = Q^T     (the lane's own Q row chunks, kept in registers)
+//   O^T[d][q]  += V^T P^T    MFMA-B = P^T taken straight from the S^T accumulators (the k index
+//                            inside one 32-deep MFMA step is permuted consistently on both
+//                            operands), MFMA-A = V^T via ds_read_b64_tr_b16 (hardware transpose)
+// One workgroup = 4 waves x 32 queries; K/V tiles of 64 keys are staged global->registers->LDS
+// one tile ahead (double buffered, one barrier per tile).  LDS rows are 128 B (64 bf16) with the
+// 16-byte chunk index XOR-swizzled by (row & 7): conflict-free for both the row reads and the
+// transposed reads.
+//
+// Backward (recompute, two kernels, no atomics, deterministic):
+//   dq kernel : same structure as forward; per KV tile S^T, dP^T = V dO^T, dS^T = P^T(dP^T - delta),
+//               dQ^T[d][q] += K^T dS^T   (K tile read by rows for S^T and transposed for dQ^T)
+//   dkv kernel: one workgroup = 4 waves x 32 keys; loops over 64-query tiles (Q, dO, lse, delta in
+//               LDS); S[q][key] = Q K^T, dP = dO V^T (query-major, key on the lane),
+//               dV^T[d][key] += dO^T P, dK^T[d][key] += Q^T dS  (P/dS from accumulators, Q/dO
+//               tiles read by rows and transposed).
 #include "common.h"
 
-int nvit_attn_fwd_mfma(const void*, const void*, const void*, float, void*, float*, int, int, int, int, int,
-                       hipStream_t) {
-  NVIT_FAIL(NVIT_EINVAL, "attn_fwd: MFMA kernel not built");
+namespace {
+
+constexpr int D = 64;         // head dim
+constexpr int ROWB = D * 2;   // bytes per LDS row
+constexpr int TKV = 64;       // rows per staged tile
+constexpr int TILE_BYTES = TKV * ROWB;  // 8 KiB
+constexpr float LOG2E = 1.4426950408889634f;
+
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ int swz_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
+
+__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
-int nvit_attn_bwd_mfma(const void*, const void*, const void*, const void*, const float*, const float*, float, void*,
-                       void*, void*, int, int, int, int, int, hipStream_t) {
-  NVIT_FAIL(NVIT_EINVAL, "attn_bwd: MFMA kernel not built");
+
+// transposed fragment: element j<4 = tile[row0 + 4*lg + j][col0 + l15], j>=4 = tile[row0 + 16 + 4*lg + (j-4)][..]
+// (the k-slot order matching accumulators of two adjacent 16-row MFMA tiles used as the other operand)
+__device__ __forceinline__ uint4 tr_frag(const char* tile, int row0, int col0, int l15, int lg) {
+  const int q = l15 >> 2, p = l15 & 3;
+  const int r0 = row0 + 4 * lg + q, r1 = r0 + 16;
+  const int ch = (col0 >> 3) + (p >> 1);
+  const int o0 = swz_off(r0, ch) + ((p & 1) << 3), o1 = swz_off(r1, ch) + ((p & 1) << 3);
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + o0));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(tile + o1));
+  uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+  return make_uint4(l2.x, l2.y, h2.x, h2.y);
+}
+
+// row fragment: tile[row0 + l15][32*ks + 8*lg .. +7]
+__device__ __forceinline__ uint4 row_frag(const char* tile, int row0, int ks, int l15, int lg) {
+  return *reinterpret_cast<const uint4*>(tile + swz_off(row0 + l15, ks * 4 + lg));
+}
+
+__device__ __forceinline__ uint4 pack8(const f32x4& a, const f32x4& b) {
+  bf16x8 v = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
+  return __builtin_bit_cast(uint4, v);
+}
+
+// stage one 64-row tile (rows of 64 bf16) from `src` (row stride ld elements) : each thread 2 chunks
+struct Stage2 {
+  uint4 v[2];
+};
+__device__ __forceinline__ void stage_load(Stage2& s, const bf16* src, size_t ld, int row_base, int nrows, int tid) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int id = tid + 256 * t;
+    int row = row_base + (id >> 3);
+    row = row < nrows ? row : nrows - 1;
+    s.v[t] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + (id & 7) * 8);
+  }
+}
+__device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int id = tid + 256 * t;
+    *reinterpret_cast<uint4*>(tile + swz_off(id >> 3, id & 7)) = s.v[t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restrict__ qh, const bf16* __restrict__ kh,
+                                                             const bf16* __restrict__ vh, float scale,
+                                                             bf16* __restrict__ o, float* __restrict__ lse, int H,
+                                                             int Tq, int Tk) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];  // [buf][K|V]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int q0 = blockIdx.x * 128 + wid * 32;
+  const bf16* kbase = kh + (size_t)bh * Tk * D;
+  const bf16* vbase = vh + (size_t)bh * Tk * D;
+  const float c2 = scale * LOG2E;
+
+  uint4 qf[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    int q = q0 + 16 * f + l15;
+    q = q < Tq ? q : Tq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[f][ks] = *reinterpret_cast<const uint4*>(qh + ((size_t)bh * Tq + q) * D + ks * 32 + lg * 8);
+  }
+  f32x4 oacc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) oacc[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_[2] = {-INFINITY, -INFINITY}, l_[2] = {0.f, 0.f};
+
+  const int nt = (Tk + TKV - 1) / TKV;
+  Stage2 sk, sv;
+  stage_load(sk, kbase, D, 0, Tk, tid);
+  stage_load(sv, vbase, D, 0, Tk, tid);
+  stage_store(sk, &lds[0][0][0], tid);
+  stage_store(sv, &lds[0][1][0], tid);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    {
+      const int tn = (t + 1 < nt) ? t + 1 : t;
+      stage_load(sk, kbase, D, tn * TKV, Tk, tid);
+      stage_load(sv, vbase, D, tn * TKV, Tk, tid);
+    }
+    const char* kt = &lds[cur][0][0];
+    const char* vt = &lds[cur][1][0];
+    // S^T[kf][f] : rows = key 16kf + 4lg + r, col = query 16f + l15
+    f32x4 s[4][2];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf) {
+      const uint4 a0 = row_frag(kt, kf * 16, 0, l15, lg), a1 = row_frag(kt, kf * 16, 1, l15, lg);
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        z = mfma16(a0, qf[f][0], z);
+        s[kf][f] = mfma16(a1, qf[f][1], z);
+      }
+    }
+    const int kbase_i = t * TKV;
+    if (kbase_i + TKV > Tk) {
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kbase_i + kf * 16 + lg * 4 + r >= Tk) {
+            s[kf][0][r] = -INFINITY;
+            s[kf][1][r] = -INFINITY;
+          }
+    }
+    uint4 pf[2][2];  // [s2][f]
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float mt = -INFINITY;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[kf][f][r]);
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float mn = fmaxf(m_[f], mt);
+      const float corr = exp2f((m_[f] - mn) * c2);
+      m_[f] = mn;
+      const float mc = mn * c2;
+      float rs = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(s[kf][f][r] * c2 - mc);
+          s[kf][f][r] = p;
+          rs += p;
+        }
+      l_[f] = l_[f] * corr + rs;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) oacc[i][f] = oacc[i][f] * corr;
+      pf[0][f] = pack8(s[0][f], s[1][f]);
+      pf[1][f] = pack8(s[2][f], s[3][f]);
+    }
+    // O^T[df][f] += V^T P^T
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const uint4 va = tr_frag(vt, s2 * 32, df * 16, l15, lg);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) oacc[df][f] = mfma16(va, pf[s2][f], oacc[df][f]);
+      }
+    stage_store(sk, &lds[cur ^ 1][0][0], tid);
+    stage_store(sv, &lds[cur ^ 1][1][0], tid);
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    float l = l_[f];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const int q = q0 + 16 * f + l15;
+    if (q < Tq) {
+      const float inv = 1.0f / l;
+      bf16* op = o + ((size_t)b * Tq + q) * (H * D) + h * D + 4 * lg;
+#pragma unroll
+      for (int df = 0; df < 4; ++df) store4<bf16>(op + df * 16, oacc[df][f] * inv);
+      if (lg == 0) lse[(size_t)bh * Tq + q] = m_[f] * scale + logf(l);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dQ
+__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
+                                                                const bf16* __restrict__ kh, const bf16* __restrict__ vh,
+                                                                const float* __restrict__ lse,
+                                                                const float* __restrict__ delta, float scale,
+                                                                bf16* __restrict__ dqh, int H, int Tq, int Tk) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int q0 = blockIdx.x * 128 + wid * 32;
+  const bf16* kbase = kh + (size_t)bh * Tk * D;
+  const bf16* vbase = vh + (size_t)bh * Tk * D;
+  const float c2 = scale * LOG2E;
+
+  uint4 qf[2][2], gf[2][2];
+  float lse2[2], dl[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    int q = q0 + 16 * f + l15;
+    q = q < Tq ? q : Tq - 1;
+    lse2[f] = lse[(size_t)bh * Tq + q] * LOG2E;
+    dl[f] = delta[(size_t)bh * Tq + q];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[f][ks] = *reinterpret_cast<const uint4*>(qh + ((size_t)bh * Tq + q) * D + ks * 32 + lg * 8);
+      gf[f][ks] = *reinterpret_cast<const uint4*>(dout + ((size_t)b * Tq + q) * (H * D) + h * D + ks * 32 + lg * 8);
+    }
+  }
+  f32x4 dq[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) dq[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nt = (Tk + TKV - 1) / TKV;
+  Stage2 sk, sv;
+  stage_load(sk, kbase, D, 0, Tk, tid);
+  stage_load(sv, vbase, D, 0, Tk, tid);
+  stage_store(sk, &lds[0][0][0], tid);
+  stage_store(sv, &lds[0][1][0], tid);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    {
+      const int tn = (t + 1 < nt) ? t + 1 : t;
+      stage_load(sk, kbase, D, tn * TKV, Tk, tid);
+      stage_load(sv, vbase, D, tn * TKV, Tk, tid);
+    }
+    const char* kt = &lds[cur][0][0];
+    const char* vt = &lds[cur][1][0];
+    const int kbase_i = t * TKV;
+    uint4 dsf[2][2];  // [s2][f]
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f32x4 ds_[2][2];  // [kk][f] for key frags kf = 2*s2 + kk
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int kf = 2 * s2 + kk;
+        const uint4 a0 = row_frag(kt, kf * 16, 0, l15, lg), a1 = row_frag(kt, kf * 16, 1, l15, lg);
+        const uint4 v0 = row_frag(vt, kf * 16, 0, l15, lg), v1 = row_frag(vt, kf * 16, 1, l15, lg);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          z = mfma16(a0, qf[f][0], z);
+          z = mfma16(a1, qf[f][1], z);  // S^T
+          f32x4 w = {0.f, 0.f, 0.f, 0.f};
+          w = mfma16(v0, gf[f][0], w);
+          w = mfma16(v1, gf[f][1], w);  // dP^T
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool valid = (kbase_i + kf * 16 + lg * 4 + r) < Tk;
+            const float p = valid ? exp2f(z[r] * c2 - lse2[f]) : 0.f;
+            ds_[kk][f][r] = p * (w[r] - dl[f]) * scale;
+          }
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < 2; ++f) dsf[s2][f] = pack8(ds_[0][f], ds_[1][f]);
+    }
+    // dQ^T[df][f] += K^T dS^T
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const uint4 ka = tr_frag(kt, s2 * 32, df * 16, l15, lg);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) dq[df][f] = mfma16(ka, dsf[s2][f], dq[df][f]);
+      }
+    stage_store(sk, &lds[cur ^ 1][0][0], tid);
+    stage_store(sv, &lds[cur ^ 1][1][0], tid);
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int q = q0 + 16 * f + l15;
+    if (q < Tq) {
+      bf16* op = dqh + ((size_t)bh * Tq + q) * D + 4 * lg;
+#pragma unroll
+      for (int df = 0; df < 4; ++df) store4<bf16>(op + df * 16, dq[df][f]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ dK, dV
+__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
+                                                                 const bf16* __restrict__ kh, const bf16* __restrict__ vh,
+                                                                 const float* __restrict__ lse,
+                                                                 const float* __restrict__ delta, float scale,
+                                                                 bf16* __restrict__ dkh, bf16* __restrict__ dvh, int H,
+                                                                 int Tq, int Tk) {
+  __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];  // [buf][Q|dO]
+  __shared__ __attribute__((aligned(16))) float stat[2][2][TKV];       // [buf][lse2|delta]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh % H;
+  const int k0 = blockIdx.x * 128 + wid * 32;
+  const bf16* qbase = qh + (size_t)bh * Tq * D;
+  const bf16* gbase = dout + (size_t)b * Tq * (H * D) + h * D;
+  const float c2 = scale * LOG2E;
+
+  uint4 kf_[2][2], vf_[2][2];  // [key frag][ks]: K / V rows of this wave's 32 keys (MFMA-B operands)
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    int k = k0 + 16 * f + l15;
+    k = k < Tk ? k : Tk - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf_[f][ks] = *reinterpret_cast<const uint4*>(kh + ((size_t)bh * Tk + k) * D + ks * 32 + lg * 8);
+      vf_[f][ks] = *reinterpret_cast<const uint4*>(vh + ((size_t)bh * Tk + k) * D + ks * 32 + lg * 8);
+    }
+  }
+  f32x4 dk[4][2], dv[4][2];  // [df][key frag]: rows d = 16df + 4lg + r, col key = l15
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      dk[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+  const int nt = (Tq + TKV - 1) / TKV;
+  Stage2 sq, sg;
+  float st_l = 0.f, st_d = 0.f;
+  auto stat_load = [&](int tq0) {
+    if (tid < TKV) {
+      const int q = tq0 + tid;
+      const bool ok = q < Tq;
+      st_l = ok ? lse[(size_t)bh * Tq + q] * LOG2E : INFINITY;  // exp2(x - inf) = 0 for padded queries
+      st_d = ok ? delta[(size_t)bh * Tq + q] : 0.f;
+    }
+  };
+  stage_load(sq, qbase, D, 0, Tq, tid);
+  stage_load(sg, gbase, (size_t)H * D, 0, Tq, tid);
+  stat_load(0);
+  stage_store(sq, &lds[0][0][0], tid);
+  stage_store(sg, &lds[0][1][0], tid);
+  if (tid < TKV) {
+    stat[0][0][tid] = st_l;
+    stat[0][1][tid] = st_d;
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    {
+      const int tn = (t + 1 < nt) ? t + 1 : t;
+      stage_load(sq, qbase, D, tn * TKV, Tq, tid);
+      stage_load(sg, gbase, (size_t)H * D, tn * TKV, Tq, tid);
+      stat_load(tn * TKV);
+    }
+    const char* qt = &lds[cur][0][0];
+    const char* gt = &lds[cur][1][0];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      f32x4 p_[2][2], ds_[2][2];  // [qq][key frag]; query frag qfi = 2*s2 + qq, rows q = 16qfi + 4lg + r
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int qfi = 2 * s2 + qq;
+        const uint4 a0 = row_frag(qt, qfi * 16, 0, l15, lg), a1 = row_frag(qt, qfi * 16, 1, l15, lg);
+        const uint4 g0 = row_frag(gt, qfi * 16, 0, l15, lg), g1 = row_frag(gt, qfi * 16, 1, l15, lg);
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&stat[cur][0][qfi * 16 + 4 * lg]);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&stat[cur][1][qfi * 16 + 4 * lg]);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          z = mfma16(a0, kf_[f][0], z);
+          z = mfma16(a1, kf_[f][1], z);  // S[q][key]
+          f32x4 w = {0.f, 0.f, 0.f, 0.f};
+          w = mfma16(g0, vf_[f][0], w);
+          w = mfma16(g1, vf_[f][1], w);  // dP[q][key]
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = exp2f(z[r] * c2 - l4[r]);
+            p_[qq][f][r] = p;
+            ds_[qq][f][r] = p * (w[r] - d4[r]) * scale;
+          }
+        }
+      }
+      uint4 pb[2], sb[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        pb[f] = pack8(p_[0][f], p_[1][f]);
+        sb[f] = pack8(ds_[0][f], ds_[1][f]);
+      }
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        const uint4 ga = tr_frag(gt, s2 * 32, df * 16, l15, lg);  // dO^T[d][q slots]
+        const uint4 qa = tr_frag(qt, s2 * 32, df * 16, l15, lg);  // Q^T[d][q slots]
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          dv[df][f] = mfma16(ga, pb[f], dv[df][f]);
+          dk[df][f] = mfma16(qa, sb[f], dk[df][f]);
+        }
+      }
+    }
+    stage_store(sq, &lds[cur ^ 1][0][0], tid);
+    stage_store(sg, &lds[cur ^ 1][1][0], tid);
+    if (tid < TKV) {
+      stat[cur ^ 1][0][tid] = st_l;
+      stat[cur ^ 1][1][tid] = st_d;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int k = k0 + 16 * f + l15;
+    if (k < Tk) {
+      bf16* kp = dkh + ((size_t)bh * Tk + k) * D + 4 * lg;
+      bf16* vp = dvh + ((size_t)bh * Tk + k) * D + 4 * lg;
+#pragma unroll
+      for (int df = 0; df < 4; ++df) {
+        store4<bf16>(kp + df * 16, dk[df][f]);
+        store4<bf16>(vp + df * 16, dv[df][f]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int nvit_attn_fwd_mfma(const void* qh, const void* kh, const void* vh, float scale, void* o, float* lse, int B, int H,
+                       int Tq, int Tk, int d, hipStream_t s) {
+  NVIT_REQUIRE(d == 64, "attn_fwd: the MFMA kernel supports head dim 64 only (got %d)", d);
+  dim3 grid(cdiv(Tq, 128), B * H);
+  hipLaunchKernelGGL(attn_fwd_mfma_kernel, grid, dim3(256), 0, s, (const bf16*)qh, (const bf16*)kh, (const bf16*)vh,
+                     scale, (bf16*)o, lse, H, Tq, Tk);
+  NVIT_CHECK_LAUNCH("attn_fwd_mfma");
+  return NVIT_OK;
+}
+
+int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const void* vh, const float* lse,
+                       const float* delta, float scale, void* dqh, void* dkh, void* dvh, int B, int H, int Tq, int Tk,
+                       int d, hipStream_t s) {
+  NVIT_REQUIRE(d == 64, "attn_bwd: the MFMA kernel supports head dim 64 only (got %d)", d);
+  dim3 gq(cdiv(Tq, 128), B * H), gk(cdiv(Tk, 128), B * H);
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, gq, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh, (const bf16*)kh,
+                     (const bf16*)vh, lse, delta, scale, (bf16*)dqh, H, Tq, Tk);
+  NVIT_CHECK_LAUNCH("attn_bwd_dq_mfma");
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh, (const bf16*)kh,
+                     (const bf16*)vh, lse, delta, scale, (bf16*)dkh, (bf16*)dvh, H, Tq, Tk);
+  NVIT_CHECK_LAUNCH("attn_bwd_dkv_mfma");
+  return NVIT_OK;
 }

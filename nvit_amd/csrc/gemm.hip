@@ -108,8 +108,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs g) {
 
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) {
-      const size_t ko = (size_t)(t + 1) * BK * sizeof(T);
+    {
+      // prefetch stage t+1 into registers (the last iteration re-loads its own stage: no branch,
+      // so the staging registers stay in VGPRs and the loads stay in flight under the MFMAs)
+      const int tnext = (t + 1 < nt) ? (t + 1) : t;
+      const size_t ko = (size_t)tnext * BK * sizeof(T);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         ra[i] = *reinterpret_cast<const uint4*>(ap[i] + ko);
@@ -137,11 +140,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) Mma<T>::run(fb[j], fa[i], acc[i][j]);
     }
-    if (t + 1 < nt) {
+    {
+      char* wa = &lds[cur ^ 1][0][0];
+      char* wb = &lds[cur ^ 1][1][0];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<uint4*>(&lds[cur ^ 1][0][soff + i * 32 * ROWB]) = ra[i];
-        *reinterpret_cast<uint4*>(&lds[cur ^ 1][1][soff + i * 32 * ROWB]) = rb[i];
+        *reinterpret_cast<uint4*>(wa + soff + i * 32 * ROWB) = ra[i];
+        *reinterpret_cast<uint4*>(wb + soff + i * 32 * ROWB) = rb[i];
       }
     }
     __syncthreads();
@@ -252,23 +257,27 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
   if (mend > g.Mred) mend = g.Mred;
   const int nt = (mend - mbeg + RB - 1) / RB;
 
-  // staging: chunk q = tid + 256*i : row = q / CHUNKS, chunk = q % CHUNKS
-  int srow[LPT], sch[LPT];
+  // staging: chunk q = tid + 256*i : row = q / CHUNKS, chunk = q % CHUNKS.  Out-of-range rows /
+  // columns are loaded from a clamped (valid) address and zeroed by a select, so there is no
+  // branch around any load.
+  int soffs[LPT];
+  size_t aoff[LPT], boff[LPT];
+  int srow[LPT];
   bool a_ok[LPT], b_ok[LPT];
 #pragma unroll
   for (int i = 0; i < LPT; ++i) {
     const int q = tid + 256 * i;
     srow[i] = q / CHUNKS;
-    sch[i] = q % CHUNKS;
-    a_ok[i] = (n0 + sch[i] * EPC) < g.N;  // N, K are multiples of EPC (checked on host)
-    b_ok[i] = (k0 + sch[i] * EPC) < g.K;
-  }
-  auto lds_off = [&](int row, int ch) -> int {
+    const int ch = q % CHUNKS;
+    a_ok[i] = (n0 + ch * EPC) < g.N;  // N, K are multiples of EPC (checked on host)
+    b_ok[i] = (k0 + ch * EPC) < g.K;
+    aoff[i] = (size_t)(a_ok[i] ? n0 + ch * EPC : 0) * sizeof(T);
+    boff[i] = (size_t)(b_ok[i] ? k0 + ch * EPC : 0) * sizeof(T);
     if constexpr (sizeof(T) == 2)
-      return row * ROW_BYTES + ((ch ^ tn_swz(row)) << 4);
+      soffs[i] = srow[i] * ROW_BYTES + ((ch ^ tn_swz(srow[i])) << 4);
     else
-      return row * ROW_BYTES + (ch << 4);
-  };
+      soffs[i] = srow[i] * ROW_BYTES + (ch << 4);
+  }
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -277,36 +286,34 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   uint4 ra[LPT], rb[LPT];
-  auto gload = [&](int t) {
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) {
-      const int m = mbeg + t * RB + srow[i];
-      const bool mok = m < mend;
-      ra[i] = (mok && a_ok[i])
-                  ? *reinterpret_cast<const uint4*>(g.A + ((size_t)m * g.lda + n0 + sch[i] * EPC) * sizeof(T))
-                  : make_uint4(0, 0, 0, 0);
-      rb[i] = (mok && b_ok[i])
-                  ? *reinterpret_cast<const uint4*>(g.B + ((size_t)m * g.ldb + k0 + sch[i] * EPC) * sizeof(T))
-                  : make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) {
-      const int o = lds_off(srow[i], sch[i]);
-      *reinterpret_cast<uint4*>(&lds[buf][0][o]) = ra[i];
-      *reinterpret_cast<uint4*>(&lds[buf][1][o]) = rb[i];
-    }
-  };
-
-  if (nt > 0) {
-    gload(0);
-    lstore(0);
+#define TN_GLOAD(t_)                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < LPT; ++i) {                                                    \
+    const int m = mbeg + (t_) * RB + srow[i];                                                          \
+    const bool mok = m < mend;                                                                         \
+    const size_t mr = (size_t)(mok ? m : (g.Mred - 1));                                                \
+    uint4 va = *reinterpret_cast<const uint4*>(g.A + mr * g.lda * sizeof(T) + aoff[i]);                \
+    uint4 vb = *reinterpret_cast<const uint4*>(g.B + mr * g.ldb * sizeof(T) + boff[i]);                \
+    const unsigned ma = (mok && a_ok[i]) ? 0xFFFFFFFFu : 0u, mb = (mok && b_ok[i]) ? 0xFFFFFFFFu : 0u; \
+    va.x &= ma; va.y &= ma; va.z &= ma; va.w &= ma;                                                    \
+    vb.x &= mb; vb.y &= mb; vb.z &= mb; vb.w &= mb;                                                    \
+    ra[i] = va;                                                                                        \
+    rb[i] = vb;                                                                                        \
   }
+#define TN_LSTORE(buf_)                                                                                \
+  _Pragma("unroll") for (int i = 0; i < LPT; ++i) {                                                    \
+    *reinterpret_cast<uint4*>(&lds[buf_][0][soffs[i]]) = ra[i];                                        \
+    *reinterpret_cast<uint4*>(&lds[buf_][1][soffs[i]]) = rb[i];                                        \
+  }
+
+  TN_GLOAD(0)
+  TN_LSTORE(0)
   __syncthreads();
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) gload(t + 1);
+    {
+      const int tnext = (t + 1 < nt) ? (t + 1) : t;
+      TN_GLOAD(tnext)
+    }
     const char* la = &lds[cur][0][0];  // A tile: [m][n]   -> MFMA B operand (cols = n)
     const char* lb = &lds[cur][1][0];  // B tile: [m][k']  -> MFMA A operand (rows = k')
     if constexpr (sizeof(T) == 2) {
@@ -365,10 +372,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[i], fa[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (t + 1 < nt) lstore(cur ^ 1);
+    TN_LSTORE(cur ^ 1)
     __syncthreads();
     cur ^= 1;
   }
+#undef TN_GLOAD
+#undef TN_LSTORE
 
   // acc[i][j][r] = G[n = n0 + wc*64 + 16j + l15][k' = k0 + wr*64 + 16i + 4lg + r]
   float* out = g.ws + (size_t)split * g.N * g.K;

@@ -615,8 +615,9 @@ class ViT(nn.Module):
         return self
 
     def _attn_impl(self) -> int:
-        if self.attn_impl == "auto":
-            return 1 if (self.precision == "bf16" and _mfma_attn_available()) else 0
+        if self.attn_impl == "auto":  # MFMA flash kernels: bf16, head dim 64; otherwise the scalar-FMA kernels
+            d = self.config.n_embd // self.config.n_head
+            return 1 if (self.precision == "bf16" and d == 64) else 0
         return int(self.attn_impl)
 
     def _prepare(self, device) -> None:
@@ -690,13 +691,3 @@ class ViT(nn.Module):
             raw = ops.gemm_nt(x_lo, rt.sh["rec.W"], B * T, Kl, C, bias=self.reconstruction_head[0].bias)
             aux["reconstruction"] = ops.recon_loss(raw, img, cfg.local_patch_size)
         return logits, aux
-
-
-_MFMA_ATTN = None
-
-
-def _mfma_attn_available() -> bool:
-    global _MFMA_ATTN
-    if _MFMA_ATTN is None:
-        _MFMA_ATTN = os.environ.get("NVIT_MFMA_ATTN", "0") == "1"
-    return _MFMA_ATTN

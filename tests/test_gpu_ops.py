@@ -215,13 +215,17 @@ def _sdpa_ref(qh, kh, vh, scale):
     return p @ vh, torch.logsumexp(s, dim=-1)
 
 
-@pytest.mark.parametrize("dtype,impl", [(torch.float32, 0), (torch.bfloat16, 0)])
-@pytest.mark.parametrize("B,H,T,d", [(2, 2, 16, 32), (1, 3, 49, 64), (2, 2, 196, 64), (1, 1, 130, 64)])
-def test_attention_ref(dtype, impl, B, H, T, d):
+@pytest.mark.parametrize("dtype,impl", [(torch.float32, 0), (torch.bfloat16, 0), (torch.bfloat16, 1)])
+@pytest.mark.parametrize("B,H,T,d", [(2, 2, 16, 32), (1, 3, 49, 64), (2, 2, 196, 64), (1, 1, 130, 64), (2, 3, 784, 64),
+                                     (1, 2, 1, 64), (1, 1, 257, 64)])
+def test_attention(dtype, impl, B, H, T, d):
+    if impl == 1 and d != 64:
+        pytest.skip("MFMA kernel: head dim 64 only")
     ops = ops_()
     from nvit_amd.ops import dt_of
-    q = torch.nn.functional.normalize(rnd(B, H, T, d, seed=1), dim=-1).to(dtype)
-    k = torch.nn.functional.normalize(rnd(B, H, T, d, seed=2), dim=-1).to(dtype)
+    # |q|=|k|=1.3 per head: logits up to sqrt(d)*1.69 (sharper softmax than the init state)
+    q = (1.3 * torch.nn.functional.normalize(rnd(B, H, T, d, seed=1), dim=-1)).to(dtype)
+    k = (1.3 * torch.nn.functional.normalize(rnd(B, H, T, d, seed=2), dim=-1)).to(dtype)
     v = rnd(B, H, T, d, seed=3).to(dtype)
     scale = math.sqrt(d)
     qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
@@ -237,9 +241,11 @@ def test_attention_ref(dtype, impl, B, H, T, d):
     assert (lse.cpu() - lse_ref.detach()).abs().max().item() < 1e-4
     g_tok = g.permute(0, 2, 1, 3).reshape(B * T, H * d).contiguous()
     dq, dk, dv = ops.attn_bwd(dt, impl, g_tok.to(dv_), q.to(dv_), k.to(dv_), v.to(dv_), o, lse, scale)
-    tolg = 1e-5 if dtype == torch.float32 else 3e-2
-    for got, ref in ((dq, qf.grad), (dk, kf.grad), (dv, vf.grad)):
-        assert (got.float().cpu() - ref).abs().max().item() < tolg * max(1.0, ref.abs().max().item())
+    tolg = 5e-5 if dtype == torch.float32 else 3e-2
+    for name, got, ref in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
+        e = (got.float().cpu() - ref).abs().max().item()
+        lim = tolg * max(1.0, ref.abs().max().item())
+        assert e < lim, f"{name}: err {e:.3e} >= {lim:.3e}"
 
 
 def test_im2col_pool_recon():
