@@ -9,9 +9,9 @@
 // bf16: v_mfma_f32_16x16x32_bf16; fp32: v_mfma_f32_16x16x4_f32 (exact f32, used for the
 // 1e-5 parity mode).  Both element types use the same 128-byte LDS row geometry
 // (64 bf16 / 32 fp32 of K per stage), XOR-swizzled in 16-byte chunks so that every
-// ds_read_b128 fragment read is bank-conflict free.  Global->LDS staging goes through
-// registers: the loads for stage t+1 are issued before the MFMAs of stage t and written to
-// the other LDS buffer after them (one barrier per stage).
+// ds_read_b128 fragment read is bank-conflict free.  gemm_nt stages global->LDS with LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write), one stage ahead, one barrier per
+// stage (issued from inline asm so hipcc does not serialise it), in both kernels.
 //
 // Operand orientation: the MFMA "A" operand is fed from the B matrix (rows = n) and the "B"
 // operand from the A matrix (cols = m), so each lane ends up with 4 CONSECUTIVE n of one
@@ -59,6 +59,17 @@ struct Mma<float> {
   }
 };
 
+// LDS-DMA of 16 bytes per lane: LDS destination = lds_off (wave-uniform, in M0) + lane*16.
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_off) {
+  unsigned keep;
+  const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_off);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(m)
+      : "memory");
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs g) {
   __shared__ __attribute__((aligned(16))) char lds[2][2][BM * ROWB];  // [buf][A|B] = 64 KiB
@@ -67,24 +78,44 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
   const int l15 = lane & 15, lg = lane >> 4;
-  const int tm = blockIdx.x / g.tiles_n, tn = blockIdx.x % g.tiles_n;
+  // Tile order.  Workgroups are dealt round-robin to the 8 XCDs (private 4 MiB L2 each), so block
+  // ids are first re-dealt such that every XCD owns ONE contiguous range of the tile sequence
+  // (bijective for any grid size), and the sequence itself walks 8(m) x tiles_n super-columns in
+  // m-fastest order: the 64 workgroups resident on an XCD then share 8 A panels and 8 B panels
+  // through L2 instead of re-fetching them from HBM/Infinity Cache.
+  int tm, tn;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GM = 8;
+    const int per_group = GM * g.tiles_n;
+    const int group = pid / per_group, first_m = group * GM;
+    const int tiles_m = nwg / g.tiles_n;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = pid - group * per_group;
+    tm = first_m + in_g % gsz;
+    tn = in_g / gsz;
+  }
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // staging map: thread -> rows (tid>>3)+32*i, global chunk tid&7, LDS slot gc ^ (row&7)
-  const int srow = tid >> 3, gc = tid & 7;
-  const int sslot = gc ^ (srow & 7);
+  // staging: LDS-DMA (global_load_lds_dwordx4).  One wave-instruction fills 1 KiB = 8 LDS rows:
+  // lane L lands at row 8*grp + (L>>3), 16-byte slot L&7, so to realise the XOR swizzle the lane
+  // FETCHES global chunk (L&7) ^ (row&7) of its row (the 128-byte line stays fully coalesced).
+  // Wave w issues groups grp = 4*i + w, i = 0..3, for each operand.
+  const int srow = lane >> 3;
+  const int gc = (lane & 7) ^ srow;
   const char* ap[4];
   const char* bp[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int ra = m0 + srow + 32 * i;
+    int ra = m0 + (i * 4 + wid) * 8 + srow;
     ra = ra < g.M ? ra : g.M - 1;
-    int rb = n0 + srow + 32 * i;
+    int rb = n0 + (i * 4 + wid) * 8 + srow;
     rb = rb < g.N ? rb : g.N - 1;
     ap[i] = g.A + ((size_t)ra * g.lda + (size_t)gc * EPC) * sizeof(T);
     bp[i] = g.B + ((size_t)rb * g.ldb + (size_t)gc * EPC) * sizeof(T);
   }
-  const int soff = srow * ROWB + sslot * 16;
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -92,33 +123,30 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[4], rb[4];
   const int nt = g.K / BK;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ra[i] = *reinterpret_cast<const uint4*>(ap[i]);
-    rb[i] = *reinterpret_cast<const uint4*>(bp[i]);
+  // The DMA is issued from inline asm so that hipcc does not serialise it: with the builtin the
+  // compiler waits vmcnt(0) before the very next ds_read (it cannot see that the DMA targets the
+  // OTHER buffer).  We wait ourselves, once per stage, right before the barrier.
+  const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)&lds[0][0][0]);
+  const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wid * 8 * ROWB);
+#define NT_STAGE(buf_, t_)                                                                              \
+  {                                                                                                     \
+    const size_t ko = (size_t)(t_) * BK * sizeof(T);                                                    \
+    const unsigned bo = lds_base + wave_off + (unsigned)(buf_) * (2 * BM * ROWB);                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+      glds16(ap[i] + ko, bo + i * 32 * ROWB);                                                           \
+      glds16(bp[i] + ko, bo + BM * ROWB + i * 32 * ROWB);                                               \
+    }                                                                                                   \
   }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    *reinterpret_cast<uint4*>(&lds[0][0][soff + i * 32 * ROWB]) = ra[i];
-    *reinterpret_cast<uint4*>(&lds[0][1][soff + i * 32 * ROWB]) = rb[i];
-  }
+  NT_STAGE(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    {
-      // prefetch stage t+1 into registers (the last iteration re-loads its own stage: no branch,
-      // so the staging registers stay in VGPRs and the loads stay in flight under the MFMAs)
-      const int tnext = (t + 1 < nt) ? (t + 1) : t;
-      const size_t ko = (size_t)tnext * BK * sizeof(T);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra[i] = *reinterpret_cast<const uint4*>(ap[i] + ko);
-        rb[i] = *reinterpret_cast<const uint4*>(bp[i] + ko);
-      }
-    }
+    // stage t+1 streams into the other buffer while stage t is consumed (the last iteration
+    // re-fetches its own stage into the idle buffer: branch-free, never read)
+    NT_STAGE(cur ^ 1, (t + 1 < nt) ? (t + 1) : t)
     const char* la = &lds[cur][0][0];
     const char* lb = &lds[cur][1][0];
 #pragma unroll
@@ -140,19 +168,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs g) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) Mma<T>::run(fb[j], fa[i], acc[i][j]);
     }
-    {
-      char* wa = &lds[cur ^ 1][0][0];
-      char* wb = &lds[cur ^ 1][1][0];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        *reinterpret_cast<uint4*>(wa + soff + i * 32 * ROWB) = ra[i];
-        *reinterpret_cast<uint4*>(wb + soff + i * 32 * ROWB) = rb[i];
-      }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
   }
 
+#undef NT_STAGE
   // epilogue: acc[i][j][r] = C[m0 + wr*64 + 16i + l15][n0 + wc*64 + 16j + 4*lg + r]
   const bool vec_ok = ((g.N & 3) == 0) && ((g.ldc & 3) == 0);
 #pragma unroll
@@ -212,6 +233,7 @@ struct TnArgs {
   const char* A;  // [Mred, N]
   const char* B;  // [Mred, K]
   float* ws;      // [splits, N, K]
+  const float* zeros;  // >= 16 bytes of zeros (tail rows / columns are fetched from here)
   int Mred, N, K;
   int lda, ldb;
   int rows_per_split;
@@ -257,27 +279,30 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
   if (mend > g.Mred) mend = g.Mred;
   const int nt = (mend - mbeg + RB - 1) / RB;
 
-  // staging: chunk q = tid + 256*i : row = q / CHUNKS, chunk = q % CHUNKS.  Out-of-range rows /
-  // columns are loaded from a clamped (valid) address and zeroed by a select, so there is no
-  // branch around any load.
-  int soffs[LPT];
-  size_t aoff[LPT], boff[LPT];
+  // staging by LDS-DMA: one wave-instruction = 1 KiB = RPI rows of the [m][col] tile; lane L lands at
+  // row L / CHUNKS, slot L % CHUNKS and therefore fetches global chunk slot ^ swz(row) (bf16).
+  // Rows past the split's end and columns past N / K are fetched from a 16-byte block of zeros.
+  constexpr int RPI = 1024 / ROW_BYTES;  // rows per wave-instruction: 4 (bf16) / 2 (fp32)
+  const int lrow = lane / CHUNKS, lslot = lane % CHUNKS;
   int srow[LPT];
+  const char* abase[LPT];
+  const char* bbase[LPT];
   bool a_ok[LPT], b_ok[LPT];
 #pragma unroll
   for (int i = 0; i < LPT; ++i) {
-    const int q = tid + 256 * i;
-    srow[i] = q / CHUNKS;
-    const int ch = q % CHUNKS;
+    srow[i] = (i * 4 + wid) * RPI + lrow;
+    int ch;
+    if constexpr (sizeof(T) == 2)
+      ch = lslot ^ tn_swz(srow[i]);
+    else
+      ch = lslot;
     a_ok[i] = (n0 + ch * EPC) < g.N;  // N, K are multiples of EPC (checked on host)
     b_ok[i] = (k0 + ch * EPC) < g.K;
-    aoff[i] = (size_t)(a_ok[i] ? n0 + ch * EPC : 0) * sizeof(T);
-    boff[i] = (size_t)(b_ok[i] ? k0 + ch * EPC : 0) * sizeof(T);
-    if constexpr (sizeof(T) == 2)
-      soffs[i] = srow[i] * ROW_BYTES + ((ch ^ tn_swz(srow[i])) << 4);
-    else
-      soffs[i] = srow[i] * ROW_BYTES + (ch << 4);
+    abase[i] = g.A + ((size_t)(mbeg + srow[i]) * g.lda + (a_ok[i] ? n0 + ch * EPC : 0)) * sizeof(T);
+    bbase[i] = g.B + ((size_t)(mbeg + srow[i]) * g.ldb + (b_ok[i] ? k0 + ch * EPC : 0)) * sizeof(T);
   }
+  const size_t astep = (size_t)RB * g.lda * sizeof(T), bstep = (size_t)RB * g.ldb * sizeof(T);
+  const char* zsrc = reinterpret_cast<const char*>(g.zeros);
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -285,35 +310,26 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[LPT], rb[LPT];
-#define TN_GLOAD(t_)                                                                                   \
-  _Pragma("unroll") for (int i = 0; i < LPT; ++i) {                                                    \
-    const int m = mbeg + (t_) * RB + srow[i];                                                          \
-    const bool mok = m < mend;                                                                         \
-    const size_t mr = (size_t)(mok ? m : (g.Mred - 1));                                                \
-    uint4 va = *reinterpret_cast<const uint4*>(g.A + mr * g.lda * sizeof(T) + aoff[i]);                \
-    uint4 vb = *reinterpret_cast<const uint4*>(g.B + mr * g.ldb * sizeof(T) + boff[i]);                \
-    const unsigned ma = (mok && a_ok[i]) ? 0xFFFFFFFFu : 0u, mb = (mok && b_ok[i]) ? 0xFFFFFFFFu : 0u; \
-    va.x &= ma; va.y &= ma; va.z &= ma; va.w &= ma;                                                    \
-    vb.x &= mb; vb.y &= mb; vb.z &= mb; vb.w &= mb;                                                    \
-    ra[i] = va;                                                                                        \
-    rb[i] = vb;                                                                                        \
-  }
-#define TN_LSTORE(buf_)                                                                                \
-  _Pragma("unroll") for (int i = 0; i < LPT; ++i) {                                                    \
-    *reinterpret_cast<uint4*>(&lds[buf_][0][soffs[i]]) = ra[i];                                        \
-    *reinterpret_cast<uint4*>(&lds[buf_][1][soffs[i]]) = rb[i];                                        \
+  const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)&lds[0][0][0]);
+  const unsigned wave_off = (unsigned)__builtin_amdgcn_readfirstlane(wid * 1024);
+#define TN_STAGE(buf_, t_)                                                                              \
+  {                                                                                                     \
+    const unsigned bo = lds_base + wave_off + (unsigned)(buf_) * (2 * TILE_BYTES);                      \
+    _Pragma("unroll") for (int i = 0; i < LPT; ++i) {                                                   \
+      const bool mok = (mbeg + (t_) * RB + srow[i]) < mend;                                             \
+      const char* pa = (mok && a_ok[i]) ? abase[i] + (size_t)(t_) * astep : zsrc;                       \
+      const char* pb = (mok && b_ok[i]) ? bbase[i] + (size_t)(t_) * bstep : zsrc;                       \
+      glds16(pa, bo + i * 4096);                                                                        \
+      glds16(pb, bo + TILE_BYTES + i * 4096);                                                           \
+    }                                                                                                   \
   }
 
-  TN_GLOAD(0)
-  TN_LSTORE(0)
+  TN_STAGE(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    {
-      const int tnext = (t + 1 < nt) ? (t + 1) : t;
-      TN_GLOAD(tnext)
-    }
+    TN_STAGE(cur ^ 1, (t + 1 < nt) ? (t + 1) : t)
     const char* la = &lds[cur][0][0];  // A tile: [m][n]   -> MFMA B operand (cols = n)
     const char* lb = &lds[cur][1][0];  // B tile: [m][k']  -> MFMA A operand (rows = k')
     if constexpr (sizeof(T) == 2) {
@@ -372,12 +388,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[i], fa[j], acc[i][j], 0, 0, 0);
       }
     }
-    TN_LSTORE(cur ^ 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
   }
-#undef TN_GLOAD
-#undef TN_LSTORE
+#undef TN_STAGE
 
   // acc[i][j][r] = G[n = n0 + wc*64 + 16j + l15][k' = k0 + wr*64 + 16i + 4lg + r]
   float* out = g.ws + (size_t)split * g.N * g.K;
@@ -473,12 +488,13 @@ extern "C" int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int l
   NVIT_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)G & 15) == 0 &&
                    ((uintptr_t)ws & 15) == 0,
                "gemm_tn: pointers must be 16-byte aligned");
-  NVIT_REQUIRE(ws_bytes >= (int64_t)splits * N * K * 4, "gemm_tn: workspace too small");
+  NVIT_REQUIRE(ws_bytes >= (int64_t)splits * N * K * 4 + 256, "gemm_tn: workspace too small (need splits*N*K*4 + 256 B)");
   NVIT_REQUIRE(perm == 0 || (perm == 1 && N % 32 == 0), "gemm_tn: perm=1 needs N %% 32 == 0");
   TnArgs g;
   g.A = (const char*)A;
   g.B = (const char*)B;
   g.ws = ws;
+  g.zeros = ws + (size_t)splits * N * K;
   g.Mred = Mred;
   g.N = N;
   g.K = K;
@@ -491,6 +507,10 @@ extern "C" int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int l
   dim3 grid((unsigned)(cdiv(N, BN) * g.tiles_k), (unsigned)splits);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(NVIT_KID_GEMM_TN, 2.0 * Mred * (double)N * K, 0.0, s);
+  {
+    hipError_t e = hipMemsetAsync(ws + (size_t)splits * N * K, 0, 256, s);
+    if (e != hipSuccess) NVIT_FAIL((int)e, "gemm_tn: memset: %s", hipGetErrorString(e));
+  }
   if (dt == NVIT_BF16)
     hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, dim3(256), 0, s, g);
   else

@@ -101,7 +101,7 @@ def gemm_tn(A: Tensor, B: Tensor, G: Tensor, Mred: int, N: int, K: int, perm: in
     ldb = B.stride(0) if ldb is None else ldb
     ldg = G.stride(0) if ldg is None else ldg
     splits = tn_splits(Mred, N, K, dt)
-    nbytes = splits * N * K * 4
+    nbytes = splits * N * K * 4 + 256
     ws = _workspace(nbytes, A.device)
     check(_lib.load().nvit_gemm_tn(dt, _p(A), lda, _p(B), ldb, _p(G), ldg, Mred, N, K, splits, _p(ws),
                                    ws.numel() * 4, perm, int(accumulate), _s()), "nvit_gemm_tn")
