@@ -54,22 +54,32 @@ __global__ __launch_bounds__(64) void attn_fwd_ref(const T* qh, const T* kh, con
   }
 }
 
-// delta[b,h,t] = sum_e dO[b,t,h*D+e] * O[b,t,h*D+e]
+// delta[b,h,t] = sum_e dO[b,t,h*D+e] * O[b,t,h*D+e].  One thread per 8 consecutive channels of a
+// token row (coalesced 16/32-byte loads); the D/8 lanes of a head are adjacent and reduce by shuffles.
 template <typename T>
-__global__ void attn_delta_kernel(const T* dout, const T* o, float* delta, int B, int H, int Tq, int D) {
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* dout, const T* o, float* delta, int B, int H,
+                                                          int Tq, int D) {
+  const int C8 = (H * D) >> 3, G = D >> 3;  // chunks per row, lanes per head (4 or 8)
+  const long long total = (long long)B * Tq * C8;
   const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  const long long total = (long long)B * H * Tq;
-  if (idx >= total) return;
-  const int t = (int)(idx % Tq);
-  const int h = (int)((idx / Tq) % H);
-  const int b = (int)(idx / ((long long)Tq * H));
-  const size_t off = ((size_t)b * Tq + t) * (H * D) + h * D;
   float s = 0.f;
-  for (int e = 0; e < D; e += 4) {
-    const f32x4 a = load4<T>(dout + off + e), c = load4<T>(o + off + e);
-    s += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+  long long m = 0;
+  int c8 = 0;
+  if (idx < total) {
+    m = idx / C8;
+    c8 = (int)(idx % C8);
+    const size_t off = (size_t)m * (H * D) + (size_t)c8 * 8;
+    const f32x4 a0 = load4<T>(dout + off), a1 = load4<T>(dout + off + 4);
+    const f32x4 b0 = load4<T>(o + off), b1 = load4<T>(o + off + 4);
+    s = a0[0] * b0[0] + a0[1] * b0[1] + a0[2] * b0[2] + a0[3] * b0[3] + a1[0] * b1[0] + a1[1] * b1[1] +
+        a1[2] * b1[2] + a1[3] * b1[3];
   }
-  delta[idx] = s;
+  s = group_sum_dyn(s, G);
+  if (idx < total && (c8 % G) == 0) {
+    const int h = c8 / G;
+    const int b = (int)(m / Tq), t = (int)(m % Tq);
+    delta[((size_t)b * H + h) * Tq + t] = s;
+  }
 }
 
 template <typename T, int D>
@@ -214,7 +224,7 @@ extern "C" int nvit_attn_bwd(int dt, int impl, const void* dout, const void* qh,
   NVIT_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "attn_bwd: empty problem");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(NVIT_KID_ATTN_BWD, 10.0 * B * H * (double)Tq * Tk * d, 0.0, s);
-  const long long total = (long long)B * H * Tq;
+  const long long total = (long long)B * Tq * ((H * d) / 8);
   if (dt == NVIT_F32)
     hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)dout,
                        (const float*)o, delta, B, H, Tq, d);

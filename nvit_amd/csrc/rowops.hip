@@ -379,12 +379,30 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* dx, const T* u
 }
 
 // ------------------------------------------------------------------------------ small reductions
-__global__ void colsum_reduce_kernel(const float* part, int nblk, int N, float* out, int accumulate, int kind,
-                                     const float* ref, float scale) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+// out[n] = f(sum_b part[b][n]); 256 threads = 32 columns x 8 row groups, fixed summation order
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* part, int nblk, int N, float* out,
+                                                             int accumulate, int kind, const float* ref, float scale) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + cl;
   float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += part[(size_t)b * N + n];
+  if (n < N) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = rg;
+    for (; b + 24 < nblk; b += 32) {
+      s0 += part[(size_t)b * N + n];
+      s1 += part[(size_t)(b + 8) * N + n];
+      s2 += part[(size_t)(b + 16) * N + n];
+      s3 += part[(size_t)(b + 24) * N + n];
+    }
+    for (; b < nblk; b += 8) s0 += part[(size_t)b * N + n];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[rg][cl] = s;
+  __syncthreads();
+  if (rg != 0 || n >= N) return;
+#pragma unroll
+  for (int g = 1; g < 8; ++g) s += red[g][cl];
   if (kind == 1) {
     const float r = ref[n] * scale;
     s = s * (r > 0.f ? scale : (r < 0.f ? -scale : 0.f));
@@ -578,7 +596,7 @@ extern "C" int nvit_colsum_reduce(const float* part, int nblk, int N, float* out
                                   const float* ref, float scale, void* stream) {
   NVIT_REQUIRE(kind == 0 || (kind == 1 && ref) || (kind == 2 && N % 32 == 0), "colsum_reduce: bad kind");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 128)), dim3(128), 0, s, part, nblk, N, out, accumulate, kind,
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 32)), dim3(256), 0, s, part, nblk, N, out, accumulate, kind,
                      ref, scale);
   NVIT_CHECK_LAUNCH("colsum_reduce");
   return NVIT_OK;

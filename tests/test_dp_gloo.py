@@ -1,0 +1,97 @@
+"""N>1 path on CPU: nvit_amd.parallel.DataParallel with the gloo backend, world_size 2.
+
+Checks the parity target of SURVEY.md §8e / §9.1-Q4: after backward every rank holds the gradient
+of the single-process run on the concatenated batch (mean of per-rank gradients), parameters that
+never receive gradients are skipped, and no_sync() defers communication across micro-steps."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.a = nn.Linear(16, 64)
+        self.unused = nn.Parameter(torch.ones(7))          # never receives a gradient (like rmsnorm_*)
+        self.b = nn.Linear(64, 300)
+        self.c = nn.Linear(300, 5)
+
+    def forward(self, x):
+        return self.c(torch.tanh(self.b(torch.tanh(self.a(x)))))
+
+
+def _data():
+    g = torch.Generator().manual_seed(1)
+    return torch.randn(8, 16, generator=g), torch.randint(0, 5, (8,), generator=g)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nvit_amd.parallel import DataParallel
+        torch.set_num_threads(1)
+        net = Net()
+        if rank == 1:  # replicas start different: construction must broadcast rank 0's parameters
+            with torch.no_grad():
+                for p in net.parameters():
+                    p.add_(1.0)
+        dp = DataParallel(net, bucket_cap_mb=0.05)  # tiny cap -> several buckets
+        X, y = _data()
+        xs, ys = X.chunk(world)[rank], y.chunk(world)[rank]
+        res = {}
+        for step in range(3):  # step 0 = discovery path, steps 1.. = overlapped bucket path
+            for p in net.parameters():
+                p.grad = None
+            nn.functional.cross_entropy(dp(xs), ys).backward()
+            res[f"step{step}"] = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+        res["buckets"] = dp.num_buckets
+        # gradient accumulation: 2 micro-steps, only the last one communicates
+        for p in net.parameters():
+            p.grad = None
+        halves = xs.chunk(2), ys.chunk(2)
+        with dp.no_sync():
+            (nn.functional.cross_entropy(dp(halves[0][0]), halves[1][0]) / 2).backward()
+        (nn.functional.cross_entropy(dp(halves[0][1]), halves[1][1]) / 2).backward()
+        res["accum"] = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_dataparallel_gloo_world2():
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    ref = Net()
+    X, y = _data()
+    nn.functional.cross_entropy(ref(X), y).backward()
+    want = {n: p.grad for n, p in ref.named_parameters()}
+    for rank in range(world):
+        res = out[rank]
+        assert res["buckets"] >= 3
+        for key in ("step0", "step1", "step2", "accum"):
+            for n, g in res[key].items():
+                if n == "unused":
+                    assert g is None
+                    continue
+                assert torch.allclose(g, want[n], atol=1e-6, rtol=1e-5), (rank, key, n)
+    # both ranks bit-identical
+    for n in want:
+        if n != "unused":
+            assert torch.equal(out[0]["step2"][n], out[1]["step2"][n])
