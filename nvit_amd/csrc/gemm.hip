@@ -16,59 +16,15 @@
 // Operand orientation: the MFMA "A" operand is fed from the B matrix (rows = n) and the "B"
 // operand from the A matrix (cols = m), so each lane ends up with 4 CONSECUTIVE n of one
 // row m: epilogue vectors (bias, column scales) are float4 loads and stores are 8/16 bytes.
-#include "common.h"
+#include <stdlib.h>
+
+#include "gemm_common.h"
+
+int nvit_gemm_nt_persistent_launch(int dt, const NtArgs& g, int tile_n, hipStream_t s);
 
 namespace {
 
 constexpr int BM = 128, BN = 128;
-constexpr int ROWB = 128;  // bytes of K per LDS row per stage
-
-struct NtArgs {
-  const char* A;
-  const char* B;
-  void* C;
-  int M, N, K;
-  int lda, ldb, ldc;  // elements
-  const float* bias;
-  const float* colscale;
-  const float* rowadd;
-  int rowadd_period;
-  int accumulate;
-  int out_dt;
-  int tiles_n;
-};
-
-template <typename T>
-struct Mma;
-template <>
-struct Mma<bf16> {
-  // one 16B chunk = 8 bf16 of K -> one 16x16x32 MFMA
-  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
-                                                  acc, 0, 0, 0);
-  }
-};
-template <>
-struct Mma<float> {
-  // one 16B chunk = 4 fp32 of K -> four 16x16x4 MFMAs (k slot = lane>>4, any consistent
-  // assignment of k to slots is valid because A and B use the same one)
-  static __device__ __forceinline__ void run(const uint4& a, const uint4& b, f32x4& acc) {
-    f32x4 fa = __builtin_bit_cast(f32x4, a), fb = __builtin_bit_cast(f32x4, b);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[t], fb[t], acc, 0, 0, 0);
-  }
-};
-
-// LDS-DMA of 16 bytes per lane: LDS destination = lds_off (wave-uniform, in M0) + lane*16.
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_off) {
-  unsigned keep;
-  const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_off);
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(m)
-      : "memory");
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs g) {
@@ -174,53 +130,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs g) {
   }
 
 #undef NT_STAGE
-  // epilogue: acc[i][j][r] = C[m0 + wr*64 + 16i + l15][n0 + wc*64 + 16j + 4*lg + r]
-  const bool vec_ok = ((g.N & 3) == 0) && ((g.ldc & 3) == 0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wr * 64 + i * 16 + l15;
-    if (m >= g.M) continue;
-    const float* radd = g.rowadd ? g.rowadd + (size_t)(m % g.rowadd_period) * g.N : nullptr;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nb = n0 + wc * 64 + j * 16 + 4 * lg;
-      if (nb >= g.N) continue;
-      f32x4 v = acc[i][j];
-      if (vec_ok) {
-        if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + nb);
-        if (g.colscale) v *= *reinterpret_cast<const f32x4*>(g.colscale + nb);
-        if (radd) v += *reinterpret_cast<const f32x4*>(radd + nb);
-        if (g.out_dt == NVIT_F32) {
-          float* cp = reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + nb;
-          if (g.accumulate) v += *reinterpret_cast<const f32x4*>(cp);
-          *reinterpret_cast<f32x4*>(cp) = v;
-        } else {
-          bf16* cp = reinterpret_cast<bf16*>(g.C) + (size_t)m * g.ldc + nb;
-          if (g.accumulate) v += load4<bf16>(cp);
-          store4<bf16>(cp, v);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int n = nb + r;
-          if (n >= g.N) break;
-          float x = v[r];
-          if (g.bias) x += g.bias[n];
-          if (g.colscale) x *= g.colscale[n];
-          if (radd) x += radd[n];
-          if (g.out_dt == NVIT_F32) {
-            float* cp = reinterpret_cast<float*>(g.C) + (size_t)m * g.ldc + n;
-            if (g.accumulate) x += *cp;
-            *cp = x;
-          } else {
-            bf16* cp = reinterpret_cast<bf16*>(g.C) + (size_t)m * g.ldc + n;
-            if (g.accumulate) x += (float)*cp;
-            *cp = (bf16)x;
-          }
-        }
-      }
-    }
-  }
+  nt_store_tile(g, acc, m0 + wr * 64, n0 + wc * 64, l15, lg);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -467,6 +377,25 @@ extern "C" int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int l
   NVIT_REQUIRE(blocks < (1ll << 31), "gemm_nt: grid too large");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(NVIT_KID_GEMM_NT, 2.0 * M * N * K, 0.0, s);
+  {
+    // large problems: persistent kernels (gemm_p.hip), 256x256 tiles when N allows, else 256x128.
+    // NVIT_GEMM_NT_IMPL=0 forces the 128x128 kernel, NVIT_GEMM_NT_TILE=128|256 forces a tile width.
+    static int impl = -1, force_tile = 0;
+    if (impl < 0) {
+      const char* e = getenv("NVIT_GEMM_NT_IMPL");
+      impl = e ? atoi(e) : 1;
+      const char* t = getenv("NVIT_GEMM_NT_TILE");
+      force_tile = t ? atoi(t) : 0;
+    }
+    if (impl == 1) {
+      const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 256), t128 = (long long)cdiv(M, 256) * cdiv(N, 128);
+      int tile = 0;
+      if (N % 256 == 0 && t256 >= 512) tile = 256;
+      else if (t128 >= 512) tile = 128;
+      if (force_tile && tile) tile = force_tile;
+      if (tile) return nvit_gemm_nt_persistent_launch(dt, g, tile, s);
+    }
+  }
   if (dt == NVIT_BF16)
     hipLaunchKernelGGL(gemm_nt_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, s, g);
   else

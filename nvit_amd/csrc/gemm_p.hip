@@ -1,0 +1,244 @@
+// Persistent NT GEMM for the large token-major GEMMs:  C[M,N] = A[M,K] * B[N,K]^T.
+//
+// Why a second kernel: with K = 768 a 128x128 tile has only 12 K-stages, so the per-tile prologue
+// (first LDS-DMA round trip) and the one-stage-ahead prefetch leave the MFMA pipes waiting on
+// L2/HBM latency, and a 128-wide tile needs ~2x the L2->LDS bytes per FLOP that a CU can sustain.
+//   * one 512-thread workgroup per CU (8 waves, 2 per SIMD) walks its tiles persistently; the stage
+//     stream is continuous across tile boundaries, so there is no per-tile prologue and the epilogue
+//     stores overlap the LDS-DMA of the next tile;
+//   * two tile shapes (template FM):  256x256 (waves 2x4, 128x64 each, 2-slot LDS ring of 64 KiB
+//     stages = 128 KiB)  and  256x128 (waves 4x2, 64x64 each, 3-slot ring of 48 KiB = 144 KiB);
+//   * per stage (BK = 64 bf16 / 32 fp32): issue DMA(s+NSLOT-1) into the slot vacated by the previous
+//     stage, 2 x (fragment reads + MFMAs), counted s_waitcnt vmcnt retiring DMA(s+1) while younger
+//     DMA stays in flight, one barrier; at a tile's last stage the epilogue re-shapes the accumulators
+//     through a private 2 KiB LDS scratch per wave so that global stores are whole 128-byte rows;
+//   * tiles are dealt so that the 32 workgroups of an XCD work on 32 consecutive tiles of an
+//     8(m) x tiles_n m-fastest walk (shared A/B panels stay in that XCD's L2).
+#include "gemm_common.h"
+
+namespace {
+
+template <int FM>
+struct PCfg;
+template <>
+struct PCfg<4> {  // 256 x 128
+  static constexpr int PBM = 256, PBN = 128, WR = 4, WC = 2, NSLOT = 3, A_DMA = 4, B_DMA = 2;
+};
+template <>
+struct PCfg<8> {  // 256 x 256
+  static constexpr int PBM = 256, PBN = 256, WR = 2, WC = 4, NSLOT = 2, A_DMA = 4, B_DMA = 4;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N == 0 || N == 6 || N == 8 || N == 12, "unsupported vmcnt");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+// EPI: 0 = generic direct epilogue, 1 = LDS-staged bf16 output, 2 = LDS-staged fp32 output
+template <typename T, int FM, int EPI>
+__global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int tiles_m, int ntiles) {
+  using Cfg = PCfg<FM>;
+  constexpr int PBM = Cfg::PBM, PBN = Cfg::PBN, NSLOT = Cfg::NSLOT;
+  constexpr int A_BYTES = PBM * ROWB, B_BYTES = PBN * ROWB, SLOT_BYTES = A_BYTES + B_BYTES;
+  constexpr int DPS = Cfg::A_DMA + Cfg::B_DMA;  // DMA wave-instructions per wave per stage
+  constexpr int WROWS = 16 * FM;                // rows of a wave's sub-tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int EPC = 16 / sizeof(T);
+  constexpr int BK = ROWB / sizeof(T);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid / Cfg::WC, wc = wid % Cfg::WC;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int nt = g.K / BK;
+  const int G = gridDim.x;  // multiple of 8
+  // workgroup -> position inside a round of G consecutive tiles: XCD x takes the x-th eighth
+  const int slot_in_round = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+  const int my_tiles = slot_in_round < ntiles ? (ntiles - slot_in_round + G - 1) / G : 0;
+  const int total_stages = my_tiles * nt;
+  if (total_stages == 0) return;
+
+  const int srow = lane >> 3;
+  const int gc = (lane & 7) ^ srow;
+  const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)smem);
+  const unsigned wave_off = (unsigned)(wid * 1024);
+
+  auto tile_of = [&](int it, int& m0, int& n0) {
+    const int pid = it * G + slot_in_round;
+    constexpr int GM = 8;
+    const int per_group = GM * g.tiles_n;
+    const int group = pid / per_group, first_m = group * GM;
+    const int gsz = (tiles_m - first_m) < GM ? (tiles_m - first_m) : GM;
+    const int in_g = pid - group * per_group;
+    m0 = (first_m + in_g % gsz) * PBM;
+    n0 = (in_g / gsz) * PBN;
+  };
+
+  // ---- load cursor: LDS-DMA, one wave-instruction = 8 rows of 128 B; wave w owns groups 8*i + w
+  const char* ap[Cfg::A_DMA];
+  const char* bp[Cfg::B_DMA];
+  int l_it = 0, l_k = 0, l_slot = 0;
+  auto set_load_tile = [&](int it) {
+    int m0, n0;
+    tile_of(it, m0, n0);
+#pragma unroll
+    for (int i = 0; i < Cfg::A_DMA; ++i) {
+      int ra = m0 + (i * 8 + wid) * 8 + srow;
+      ra = ra < g.M ? ra : g.M - 1;
+      ap[i] = g.A + ((size_t)ra * g.lda + (size_t)gc * EPC) * sizeof(T);
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::B_DMA; ++i) {
+      int rb = n0 + (i * 8 + wid) * 8 + srow;
+      rb = rb < g.N ? rb : g.N - 1;
+      bp[i] = g.B + ((size_t)rb * g.ldb + (size_t)gc * EPC) * sizeof(T);
+    }
+  };
+  auto issue_stage = [&]() {
+    const unsigned bo = lds_base + wave_off + (unsigned)l_slot * SLOT_BYTES;
+    const size_t ko = (size_t)l_k * ROWB;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_DMA; ++i) glds16(ap[i] + ko, bo + i * 8192);
+#pragma unroll
+    for (int i = 0; i < Cfg::B_DMA; ++i) glds16(bp[i] + ko, bo + A_BYTES + i * 8192);
+    l_slot = l_slot == NSLOT - 1 ? 0 : l_slot + 1;
+    if (++l_k == nt) {
+      l_k = 0;
+      ++l_it;
+      if (l_it < my_tiles) set_load_tile(l_it);
+    }
+  };
+
+  f32x4 acc[FM][4];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment reads of one k-half (kk) of the stage sitting in ring slot `slot_`
+#define LOAD_FRAGS(FA, FB, slot_, kk_)                                                          \
+  {                                                                                             \
+    const char* la_ = smem + (slot_) * SLOT_BYTES;                                              \
+    const char* lb_ = la_ + A_BYTES;                                                            \
+    const int c_ = (kk_) * 4 + lg;                                                              \
+    _Pragma("unroll") for (int i = 0; i < FM; ++i) {                                            \
+      const int r = wr * WROWS + i * 16 + l15;                                                  \
+      FA[i] = *reinterpret_cast<const uint4*>(la_ + r * ROWB + ((c_ ^ (r & 7)) << 4));          \
+    }                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
+      const int r = wc * 64 + j * 16 + l15;                                                     \
+      FB[j] = *reinterpret_cast<const uint4*>(lb_ + r * ROWB + ((c_ ^ (r & 7)) << 4));          \
+    }                                                                                           \
+  }
+#define MMA_FRAGS(FA, FB)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < FM; ++i) _Pragma("unroll") for (int j = 0; j < 4; ++j)  \
+      Mma<T>::run(FB[j], FA[i], acc[i][j]);
+
+  // prologue: NSLOT-1 stages in flight, wait for stage 0
+  set_load_tile(0);
+  issue_stage();
+  if (NSLOT > 2 && total_stages > 1) issue_stage();
+  if (NSLOT > 2 && total_stages > 1)
+    wait_vmcnt<(NSLOT > 2 ? DPS : 0)>();
+  else
+    wait_vmcnt<0>();
+  __syncthreads();
+
+  // Per stage s (ring slot s % NSLOT): issue DMA(s+NSLOT-1) into the slot vacated by stage s-1,
+  // multiply both k-halves of stage s, retire DMA(s+1) with a counted vmcnt (younger DMA stays in
+  // flight), one barrier.
+  int c_it = 0, c_k = 0;
+  int slot = 0;
+  for (int s = 0; s < total_stages; ++s) {
+    if (s + NSLOT - 1 < total_stages) issue_stage();
+    {
+      uint4 fa[FM], fb[4];
+      LOAD_FRAGS(fa, fb, slot, 0)
+      MMA_FRAGS(fa, fb)
+    }
+    {
+      uint4 fa[FM], fb[4];
+      LOAD_FRAGS(fa, fb, slot, 1)
+      MMA_FRAGS(fa, fb)
+    }
+    bool stored = false;
+    if (++c_k == nt) {
+      int m0, n0;
+      tile_of(c_it, m0, n0);
+      {
+        char* scratch = smem + NSLOT * SLOT_BYTES + wid * 2048;
+        if constexpr (EPI == 1)
+          nt_store_tile_staged<FM, bf16>(g, acc, m0 + wr * WROWS, n0 + wc * 64, lane, scratch);
+        else if constexpr (EPI == 2)
+          nt_store_tile_staged<FM, float>(g, acc, m0 + wr * WROWS, n0 + wc * 64, lane, scratch);
+        else
+          nt_store_tile<FM>(g, acc, m0 + wr * WROWS, n0 + wc * 64, l15, lg);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      c_k = 0;
+      ++c_it;
+      stored = true;
+    }
+    // retire DMA(s+1).  vmcnt counts stores too (issue order): after an epilogue drain everything.
+    if (NSLOT > 2 && s + 2 < total_stages && !stored)
+      wait_vmcnt<(NSLOT > 2 ? (NSLOT - 2) * DPS : 0)>();
+    else
+      wait_vmcnt<0>();
+    __syncthreads();
+    slot = slot == NSLOT - 1 ? 0 : slot + 1;
+  }
+#undef LOAD_FRAGS
+#undef MMA_FRAGS
+}
+
+template <typename T, int FM, int EPI>
+int launch_p2(const NtArgs& g_in, int n_cu, hipStream_t s) {
+  using Cfg = PCfg<FM>;
+  constexpr int LDS_BYTES = Cfg::NSLOT * (Cfg::PBM + Cfg::PBN) * ROWB + 8 * 2048;  // ring + epilogue scratch
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_persistent_kernel<T, FM, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) NVIT_FAIL((int)e, "gemm_nt: cannot raise LDS limit: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  NtArgs g = g_in;
+  g.tiles_n = cdiv(g.N, Cfg::PBN);
+  const int tiles_m = cdiv(g.M, Cfg::PBM);
+  hipLaunchKernelGGL((gemm_nt_persistent_kernel<T, FM, EPI>), dim3(n_cu), dim3(512), LDS_BYTES, s, g, tiles_m,
+                     tiles_m * g.tiles_n);
+  NVIT_CHECK_LAUNCH("gemm_nt_persistent");
+  return NVIT_OK;
+}
+
+template <typename T, int FM>
+int launch_p(const NtArgs& g, int n_cu, hipStream_t s) {
+  const int eo = g.out_dt == NVIT_F32 ? 4 : 8;  // output elements per 16-byte chunk
+  const bool staged = (g.N % eo) == 0 && (g.ldc % eo) == 0;
+  if (!staged) return launch_p2<T, FM, 0>(g, n_cu, s);
+  return g.out_dt == NVIT_F32 ? launch_p2<T, FM, 2>(g, n_cu, s) : launch_p2<T, FM, 1>(g, n_cu, s);
+}
+
+}  // namespace
+
+// tile_n: 128 or 256
+int nvit_gemm_nt_persistent_launch(int dt, const NtArgs& g, int tile_n, hipStream_t s) {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int devid = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&devid) != hipSuccess || hipGetDeviceProperties(&prop, devid) != hipSuccess)
+      NVIT_FAIL(NVIT_EINVAL, "gemm_nt: cannot query device properties");
+    n_cu = prop.multiProcessorCount;
+    n_cu -= n_cu % 8;
+    if (n_cu < 8) n_cu = 8;
+  }
+  if (dt == NVIT_BF16) return tile_n == 256 ? launch_p<bf16, 8>(g, n_cu, s) : launch_p<bf16, 4>(g, n_cu, s);
+  return tile_n == 256 ? launch_p<float, 8>(g, n_cu, s) : launch_p<float, 4>(g, n_cu, s);
+}

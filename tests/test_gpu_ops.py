@@ -29,7 +29,8 @@ TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 192), (777, 1000, 128), (64, 10, 64), (513, 384, 768)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 192), (777, 1000, 128), (64, 10, 64), (513, 384, 768),
+                                   (16500, 1000, 128), (33000, 520, 64), (25088, 768, 192)])  # last 3: persistent kernel
 def test_gemm_nt(dtype, M, N, K):
     ops = ops_()
     A = rnd(M, K, seed=1).to(dtype)
