@@ -21,6 +21,8 @@
 #include "gemm_common.h"
 
 int nvit_gemm_nt_persistent_launch(int dt, const NtArgs& g, int tile_n, hipStream_t s);
+int nvit_gemm_tn_persistent_launch(int dt, const void* A, int lda, const void* B, int ldb, float* ws,
+                                   const float* zeros, int Mred, int N, int K, int splits, hipStream_t s);
 
 namespace {
 
@@ -440,11 +442,28 @@ extern "C" int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int l
     hipError_t e = hipMemsetAsync(ws + (size_t)splits * N * K, 0, 256, s);
     if (e != hipSuccess) NVIT_FAIL((int)e, "gemm_tn: memset: %s", hipGetErrorString(e));
   }
-  if (dt == NVIT_BF16)
-    hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, dim3(256), 0, s, g);
-  else
-    hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, s, g);
-  NVIT_CHECK_LAUNCH("gemm_tn");
+  bool done = false;
+  {
+    // big 256-aligned weight shapes: persistent 256x256 kernel (gemm_tn_p.hip); NVIT_GEMM_TN_IMPL=0 disables
+    static int impl = -1;
+    if (impl < 0) {
+      const char* e = getenv("NVIT_GEMM_TN_IMPL");
+      impl = e ? atoi(e) : 1;
+    }
+    if (impl == 1 && Mred >= 4096) {
+      const int rc = nvit_gemm_tn_persistent_launch(dt, A, lda, B, ldb, ws, ws + (size_t)splits * N * K, Mred, N, K,
+                                                    splits, s);
+      if (rc > 0) return rc;
+      done = rc == NVIT_OK;
+    }
+  }
+  if (!done) {
+    if (dt == NVIT_BF16)
+      hipLaunchKernelGGL(gemm_tn_kernel<bf16>, grid, dim3(256), 0, s, g);
+    else
+      hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, s, g);
+    NVIT_CHECK_LAUNCH("gemm_tn");
+  }
   const long long total = (long long)N * (K / 4);
   int rblocks = cdiv(total, 256);
   if (rblocks > 4096) rblocks = 4096;

@@ -1,0 +1,291 @@
+// Persistent weight-gradient GEMM:  G[n][k'] = sum_m A[m][n] * B[m][k']   (A [Mred,N], B [Mred,K]).
+//
+// Same machine as gemm_p.hip, turned for the "both operands are reduction-major" case:
+//   * output tile 256 (n) x 256 (k'), 8 waves (2 x 4: 128 k' x 64 n each), one workgroup per CU;
+//   * work items = (output tile, row split); a workgroup walks its items persistently, the LDS-DMA
+//     stream (2-slot ring of 64 KiB stages = 64 reduction rows of both operands) is continuous
+//     across items;
+//   * tiles are stored in LDS exactly as they sit in memory ([m][col], 512-byte rows, 16-byte chunks
+//     XOR-swizzled by the row so that the transposed reads are conflict free) and the MFMA operands
+//     are fetched with ds_read_b64_tr_b16 (hardware 4x16 transpose); fp32 uses ds_read_b32;
+//   * each item writes its fp32 256x256 partial tile to the slab of its split; slab_reduce (gemm.hip)
+//     sums the splits in a fixed order (deterministic).
+// Requires N % 256 == 0 and K % 256 == 0 (the Base/Large weight shapes); other shapes use gemm_tn.
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int TBN = 256, TBK = 256;
+constexpr int OP_BYTES = 32768;           // one operand stage: 64 rows x 512 B (bf16) or 32 rows x 1 KiB (fp32)
+constexpr int TSLOT_BYTES = 2 * OP_BYTES;  // 64 KiB
+constexpr int TN_LDS = 2 * TSLOT_BYTES;    // 128 KiB
+
+struct TnpArgs {
+  const char* A;
+  const char* B;
+  float* ws;
+  const float* zeros;
+  int Mred, N, K;
+  int lda, ldb;
+  int rows_per_split, splits;
+  int tiles_n, tiles_k;
+};
+
+__device__ __forceinline__ int tnp_swz(int m) { return (((m & 3) | (((m >> 3) & 1) << 2)) << 1); }
+
+template <typename T>
+__global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int RB = sizeof(T) == 2 ? 64 : 32;       // reduction rows per stage
+  constexpr int ROW_BYTES = 256 * sizeof(T);         // 512 / 1024
+  constexpr int CHUNKS = ROW_BYTES / 16;             // 32 / 64
+  constexpr int RPI = 1024 / ROW_BYTES;              // rows per DMA wave-instruction: 2 / 1
+  constexpr int EPC = 16 / sizeof(T);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;  // wr: k' half (MFMA rows, 128 each); wc: n quarter (64 each)
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int G = gridDim.x;
+  const int tiles = g.tiles_n * g.tiles_k;
+  const int nitems = tiles * g.splits;
+  const int first = blockIdx.x;
+  const int my_items = first < nitems ? (nitems - first + G - 1) / G : 0;
+  if (my_items == 0) return;
+
+  const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)smem);
+  const unsigned wave_off = (unsigned)(wid * 1024);
+  const int lrow = lane / CHUNKS, lslot = lane % CHUNKS;
+  const char* zsrc = reinterpret_cast<const char*>(g.zeros);
+
+  // item -> (n0, k0, mbeg, mend, split)
+  auto item_of = [&](int it, int& n0, int& k0, int& mbeg, int& mend, int& split) {
+    const int id = first + it * G;
+    split = id / tiles;
+    const int tile = id - split * tiles;
+    n0 = (tile / g.tiles_k) * TBN;
+    k0 = (tile % g.tiles_k) * TBK;
+    mbeg = split * g.rows_per_split;
+    mend = mbeg + g.rows_per_split;
+    if (mend > g.Mred) mend = g.Mred;
+  };
+  auto stages_of = [&](int it) {
+    int n0, k0, mbeg, mend, split;
+    item_of(it, n0, k0, mbeg, mend, split);
+    const int rows = mend - mbeg;
+    return rows > 0 ? (rows + RB - 1) / RB : 0;
+  };
+
+  // ---- load cursor
+  const char* abase[4];
+  const char* bbase[4];
+  int srow[4];
+  int l_it = 0, l_t = 0, l_nt = 0, l_mbeg = 0, l_mend = 0, l_slot = 0;
+  size_t astep = (size_t)RB * g.lda * sizeof(T), bstep = (size_t)RB * g.ldb * sizeof(T);
+  auto set_load_item = [&](int it) {
+    int n0, k0, split;
+    item_of(it, n0, k0, l_mbeg, l_mend, split);
+    const int rows = l_mend - l_mbeg;
+    l_nt = rows > 0 ? (rows + RB - 1) / RB : 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      srow[i] = (i * 8 + wid) * RPI + lrow;
+      int ch;
+      if constexpr (sizeof(T) == 2)
+        ch = lslot ^ tnp_swz(srow[i]);
+      else
+        ch = lslot;
+      abase[i] = g.A + ((size_t)(l_mbeg + srow[i]) * g.lda + n0 + ch * EPC) * sizeof(T);
+      bbase[i] = g.B + ((size_t)(l_mbeg + srow[i]) * g.ldb + k0 + ch * EPC) * sizeof(T);
+    }
+  };
+  auto advance_to_nonempty = [&]() {
+    while (l_it < my_items && l_nt == 0) {
+      ++l_it;
+      if (l_it < my_items) set_load_item(l_it);
+    }
+  };
+  auto issue_stage = [&]() {
+    const unsigned bo = lds_base + wave_off + (unsigned)l_slot * TSLOT_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool mok = (l_mbeg + l_t * RB + srow[i]) < l_mend;
+      const char* pa = mok ? abase[i] + (size_t)l_t * astep : zsrc;
+      const char* pb = mok ? bbase[i] + (size_t)l_t * bstep : zsrc;
+      glds16(pa, bo + i * 8192);
+      glds16(pb, bo + OP_BYTES + i * 8192);
+    }
+    l_slot ^= 1;
+    if (++l_t == l_nt) {
+      l_t = 0;
+      ++l_it;
+      l_nt = 0;
+      if (l_it < my_items) {
+        set_load_item(l_it);
+        advance_to_nonempty();
+      }
+    }
+  };
+
+  // total number of stages this workgroup will process
+  int total_stages = 0;
+  for (int it = 0; it < my_items; ++it) total_stages += stages_of(it);
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // compute cursor (skips empty items, which still must write zeros to their slab tile)
+  int c_it = 0, c_t = 0, c_nt = stages_of(0);
+  auto store_item = [&](int it) {
+    int n0, k0, mbeg, mend, split;
+    item_of(it, n0, k0, mbeg, mend, split);
+    float* out = g.ws + (size_t)split * g.N * g.K;
+    // acc[i][j][r] = G[n = n0 + wc*64 + 16j + l15][k' = k0 + wr*128 + 16i + 4lg + r]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + wc * 64 + j * 16 + l15;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int kb = k0 + wr * 128 + i * 16 + 4 * lg;
+        *reinterpret_cast<f32x4*>(out + (size_t)n * g.K + kb) = acc[i][j];
+        acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  };
+  while (c_it < my_items && c_nt == 0) {  // leading empty items
+    store_item(c_it);
+    ++c_it;
+    c_nt = c_it < my_items ? stages_of(c_it) : 0;
+  }
+  if (total_stages == 0) return;
+
+  set_load_item(0);
+  advance_to_nonempty();
+  issue_stage();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int slot = 0;
+  for (int s = 0; s < total_stages; ++s) {
+    if (s + 1 < total_stages) issue_stage();  // DMA(s+1) into the other slot (vacated by stage s-1)
+    const char* la = smem + slot * TSLOT_BYTES;  // A tile: [m][n]  -> MFMA B operand (cols = n)
+    const char* lb = la + OP_BYTES;              // B tile: [m][k'] -> MFMA A operand (rows = k')
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int q = l15 >> 2, p = l15 & 3;
+        const int mrow = ks * 32 + lg * 8 + q;
+        const int s0 = tnp_swz(mrow), s1 = tnp_swz(mrow + 4);
+        uint4 fa[4], fb[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ch = ((wc * 64 + j * 16) >> 3) + (p >> 1);
+          const int o0 = mrow * ROW_BYTES + ((ch ^ s0) << 4) + ((p & 1) << 3);
+          const int o1 = (mrow + 4) * ROW_BYTES + ((ch ^ s1) << 4) + ((p & 1) << 3);
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(la + o0));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(la + o1));
+          uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          fa[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int ch = ((wr * 128 + i * 16) >> 3) + (p >> 1);
+          const int o0 = mrow * ROW_BYTES + ((ch ^ s0) << 4) + ((p & 1) << 3);
+          const int o1 = (mrow + 4) * ROW_BYTES + ((ch ^ s1) << 4) + ((p & 1) << 3);
+          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lb + o0));
+          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lb + o1));
+          uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          fb[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Mma<bf16>::run(fb[i], fa[j], acc[i][j]);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < RB / 4; ++ks) {
+        const int mrow = ks * 4 + lg;
+        float fa[4], fb[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          fa[j] = *reinterpret_cast<const float*>(la + mrow * ROW_BYTES + (wc * 64 + j * 16 + l15) * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          fb[i] = *reinterpret_cast<const float*>(lb + mrow * ROW_BYTES + (wr * 128 + i * 16 + l15) * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[i], fa[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (++c_t == c_nt) {
+      store_item(c_it);
+      ++c_it;
+      c_t = 0;
+      c_nt = c_it < my_items ? stages_of(c_it) : 0;
+      while (c_it < my_items && c_nt == 0) {  // empty items in between
+        store_item(c_it);
+        ++c_it;
+        c_nt = c_it < my_items ? stages_of(c_it) : 0;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA(s+1) landed (and any slab stores drained)
+    __syncthreads();
+    slot ^= 1;
+  }
+}
+
+}  // namespace
+
+// Returns NVIT_OK after launching, or a negative value (-1) when the shape is not eligible.
+int nvit_gemm_tn_persistent_launch(int dt, const void* A, int lda, const void* B, int ldb, float* ws,
+                                   const float* zeros, int Mred, int N, int K, int splits, hipStream_t s) {
+  if (N % TBN != 0 || K % TBK != 0) return -1;
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int devid = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&devid) != hipSuccess || hipGetDeviceProperties(&prop, devid) != hipSuccess)
+      NVIT_FAIL(NVIT_EINVAL, "gemm_tn: cannot query device properties");
+    n_cu = prop.multiProcessorCount;
+  }
+  static bool attr_set[2] = {false, false};
+  const int idx = dt == NVIT_BF16 ? 1 : 0;
+  if (!attr_set[idx]) {
+    hipError_t e = dt == NVIT_BF16 ? hipFuncSetAttribute((const void*)gemm_tn_persistent_kernel<bf16>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS)
+                                   : hipFuncSetAttribute((const void*)gemm_tn_persistent_kernel<float>,
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS);
+    if (e != hipSuccess) NVIT_FAIL((int)e, "gemm_tn: cannot raise LDS limit: %s", hipGetErrorString(e));
+    attr_set[idx] = true;
+  }
+  TnpArgs g;
+  g.A = (const char*)A;
+  g.B = (const char*)B;
+  g.ws = ws;
+  g.zeros = zeros;
+  g.Mred = Mred;
+  g.N = N;
+  g.K = K;
+  g.lda = lda;
+  g.ldb = ldb;
+  g.splits = splits;
+  const int rb = dt == NVIT_BF16 ? 64 : 32;
+  int rps = cdiv(Mred, splits);
+  rps = cdiv(rps, rb) * rb;
+  g.rows_per_split = rps;
+  g.tiles_n = N / TBN;
+  g.tiles_k = K / TBK;
+  const int nitems = g.tiles_n * g.tiles_k * splits;
+  const int grid = nitems < n_cu ? nitems : n_cu;
+  if (dt == NVIT_BF16)
+    hipLaunchKernelGGL(gemm_tn_persistent_kernel<bf16>, dim3(grid), dim3(512), TN_LDS, s, g);
+  else
+    hipLaunchKernelGGL(gemm_tn_persistent_kernel<float>, dim3(grid), dim3(512), TN_LDS, s, g);
+  NVIT_CHECK_LAUNCH("gemm_tn_persistent");
+  return NVIT_OK;
+}

@@ -85,6 +85,21 @@ def _workspace(nbytes: int, device) -> Tensor:
 
 
 def tn_splits(Mred: int, N: int, K: int, dt: int) -> int:
+    if N % 256 == 0 and K % 256 == 0 and Mred >= 4096:
+        # persistent 256x256 kernel: (tiles x splits) work items dealt over 256 workgroups; pick the
+        # split count that fills whole rounds best (fewest splits on ties: less slab traffic)
+        tiles = (N // 256) * (K // 256)
+        flops = 2.0 * Mred * N * K
+        best, best_t = 1, float("inf")
+        for s in range(1, 65):
+            if Mred // s < 1024:
+                break
+            items = tiles * s
+            eff = items / (math.ceil(items / 256) * 256)
+            t = flops / (1.0e15 * eff) + 2.0 * s * N * K * 4 / 4.0e12  # MFMA time + slab write/read
+            if t < best_t:
+                best, best_t = s, t
+        return best
     tiles = math.ceil(N / 128) * math.ceil(K / 128)
     rb = bk_of(dt)
     want = max(1, math.ceil(1024 / tiles))

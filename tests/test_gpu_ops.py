@@ -56,6 +56,7 @@ def test_gemm_nt(dtype, M, N, K):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Mred,N,K,perm", [(256, 128, 128, 0), (1000, 192, 72, 0), (5000, 256, 64, 1), (130, 64, 200, 0),
+                                           (5000, 256, 256, 0), (9001, 512, 256, 1), (20000, 256, 768, 0),
                                            (37, 40, 16, 0)])
 def test_gemm_tn(dtype, Mred, N, K, perm):
     ops = ops_()
