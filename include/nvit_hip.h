@@ -88,6 +88,21 @@ int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int ldb, void* C
                  int M, int N, int K, const float* bias, const float* colscale, const float* rowadd,
                  int rowadd_period, int accumulate, void* stream);
 
+/* Fused-epilogue variants of nvit_gemm_nt (bf16 operands; N % 256 == 0, K % 64 == 0 — query with
+ * nvit_gemm_nt_fusable; otherwise callers run nvit_gemm_nt followed by nvit_swiglu_fwd / nvit_qknorm_fwd).
+ * nvit_gemm_nt_swiglu: uv[M,2F] = A B^T with B the perm=1 (u16|v16 interleaved) shadow of c_fc / proj, AND
+ *   xm[M,F] = (gu*u)*silu(gv*v), gu/gv = gs[.]*gscale with gs = suv in the same interleaved order (NULL = 1)
+ *   (model.py:148-154: the [M,8C] pre-activation is written once, never re-read in forward).
+ * nvit_gemm_nt_qknorm: q/k/v projections (nparts stacked [C,K] weights starting at part part0: 0=q,1=k,2=v) with
+ *   the per-head L2 normalise, sqk*c_q scale and [B,H,T,64] head split done on the fp32 accumulators
+ *   (model.py:99-119); rq/rk [M,H] = 1/||.||.  Requires head dim 64 and n_embd % 256 == 0. */
+int nvit_gemm_nt_fusable(int dt, int M, int N, int K);
+int nvit_gemm_nt_swiglu(int dt, const void* A, int lda, const void* B, int ldb, void* uv, void* xm, int M, int F,
+                        int K, const float* gs, float gscale, void* stream);
+int nvit_gemm_nt_qknorm(int dt, const void* A, int lda, const void* B, int ldb, int M, int K, int nparts, int part0,
+                        const float* sqk, float c_q, void* qh, void* kh, void* vh, float* rq, float* rk, int T, int H,
+                        int d, void* stream);
+
 /* nvit_gemm_tn: weight gradient  G[N,K] (+)= sum_m A[m,N-col] * B[m,K-col]  over Mred rows.
  * A [Mred, N] (lda), B [Mred, K] (ldb) of type dt.  Split over `splits` row chunks into the
  * fp32 workspace ws [splits, N, K] (ws_bytes >= splits*N*K*4 + 256), then reduced in fixed order

@@ -21,6 +21,7 @@
 #include "gemm_common.h"
 
 int nvit_gemm_nt_persistent_launch(int dt, const NtArgs& g, int tile_n, hipStream_t s);
+int nvit_gemm_nt_fused_launch(const NtArgs& g, int epi, hipStream_t s);
 int nvit_gemm_tn_persistent_launch(int dt, const void* A, int lda, const void* B, int ldb, float* ws,
                                    const float* zeros, int Mred, int N, int K, int splits, hipStream_t s);
 
@@ -358,7 +359,7 @@ extern "C" int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int l
   NVIT_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 15) == 0,
                "gemm_nt: pointers must be 16-byte aligned");
   NVIT_REQUIRE(!rowadd || rowadd_period > 0, "gemm_nt: rowadd needs a period");
-  NtArgs g;
+  NtArgs g{};
   g.A = (const char*)A;
   g.B = (const char*)B;
   g.C = C;
@@ -471,4 +472,72 @@ extern "C" int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int l
                      accumulate);
   NVIT_CHECK_LAUNCH("slab_reduce");
   return NVIT_OK;
+}
+
+// ---- fused-epilogue GEMMs (bf16, persistent 256x256 kernel only; callers fall back to the unfused
+//      sequence nvit_gemm_nt + nvit_swiglu_fwd / nvit_qknorm_fwd when these report "not eligible") ----
+extern "C" int nvit_gemm_nt_fusable(int dt, int M, int N, int K) {
+  return (dt == NVIT_BF16 && M >= 1 && N % 256 == 0 && K % 64 == 0) ? 1 : 0;
+}
+
+extern "C" int nvit_gemm_nt_swiglu(int dt, const void* A, int lda, const void* B, int ldb, void* uv, void* xm, int M,
+                                   int F, int K, const float* gs, float gscale, void* stream) {
+  NVIT_REQUIRE(nvit_gemm_nt_fusable(dt, M, 2 * F, K), "gemm_nt_swiglu: shape/dtype not eligible for the fused kernel");
+  NVIT_REQUIRE((lda * 2) % 16 == 0 && (ldb * 2) % 16 == 0 && lda >= K && ldb >= K, "gemm_nt_swiglu: bad leading dims");
+  NVIT_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)uv | (uintptr_t)xm | (uintptr_t)gs) & 15) == 0,
+               "gemm_nt_swiglu: pointers must be 16-byte aligned");
+  NtArgs g{};
+  g.A = (const char*)A;
+  g.B = (const char*)B;
+  g.C = uv;
+  g.M = M;
+  g.N = 2 * F;
+  g.K = K;
+  g.lda = lda;
+  g.ldb = ldb;
+  g.ldc = 2 * F;
+  g.out_dt = NVIT_BF16;
+  g.xm = xm;
+  g.ld_xm = F;
+  g.gs = gs;
+  g.gscale = gscale;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(NVIT_KID_GEMM_NT, 2.0 * M * (2.0 * F) * K, 0.0, s);
+  return nvit_gemm_nt_fused_launch(g, 3, s);
+}
+
+extern "C" int nvit_gemm_nt_qknorm(int dt, const void* A, int lda, const void* B, int ldb, int M, int K, int nparts,
+                                   int part0, const float* sqk, float c_q, void* qh, void* kh, void* vh, float* rq,
+                                   float* rk, int T, int H, int d, void* stream) {
+  const int C = H * d;
+  NVIT_REQUIRE(d == 64 && C % 256 == 0 && nparts >= 1 && part0 >= 0 && part0 + nparts <= 3,
+               "gemm_nt_qknorm: needs head dim 64 and n_embd %% 256 == 0");
+  NVIT_REQUIRE(nvit_gemm_nt_fusable(dt, M, nparts * C, K), "gemm_nt_qknorm: shape/dtype not eligible");
+  NVIT_REQUIRE((lda * 2) % 16 == 0 && (ldb * 2) % 16 == 0 && lda >= K && ldb >= K, "gemm_nt_qknorm: bad leading dims");
+  NVIT_REQUIRE(M % T == 0, "gemm_nt_qknorm: M must be a multiple of T");
+  NVIT_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)qh | (uintptr_t)kh | (uintptr_t)vh | (uintptr_t)sqk) & 15) == 0,
+               "gemm_nt_qknorm: pointers must be 16-byte aligned");
+  NtArgs g{};
+  g.A = (const char*)A;
+  g.B = (const char*)B;
+  g.M = M;
+  g.N = nparts * C;
+  g.K = K;
+  g.lda = lda;
+  g.ldb = ldb;
+  g.out_dt = NVIT_BF16;
+  g.qh = qh;
+  g.kh = kh;
+  g.vh = vh;
+  g.rq = rq;
+  g.rk = rk;
+  g.sqk = sqk;
+  g.c_q = c_q;
+  g.part0 = part0;
+  g.Cemb = C;
+  g.Ttok = T;
+  g.H = H;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(NVIT_KID_GEMM_NT, 2.0 * M * (double)(nparts * C) * K, 0.0, s);
+  return nvit_gemm_nt_fused_launch(g, 4, s);
 }

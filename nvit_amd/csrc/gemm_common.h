@@ -17,6 +17,17 @@ struct NtArgs {
   int accumulate;
   int out_dt;
   int tiles_n;
+  // --- fused SwiGLU epilogue (EPI 3): C = raw uv (interleaved u16|v16 columns), xm = (gu*u)*silu(gv*v)
+  void* xm;
+  int ld_xm;
+  const float* gs;  // suv in the interleaved column order of C (or NULL = ones)
+  float gscale;
+  // --- fused q/k-normalise epilogue (EPI 4): columns are nparts stacked [C]-wide projections
+  void *qh, *kh, *vh;  // [B,H,T,64] bf16
+  float *rq, *rk;      // [M,H] 1/||.||
+  const float* sqk;
+  float c_q;
+  int part0, Cemb, Ttok, H;
 };
 
 template <typename T>
@@ -169,6 +180,115 @@ __device__ __forceinline__ void nt_store_tile_staged(const NtArgs& g, f32x4 (&ac
             *reinterpret_cast<uint4*>(cp) = raw;
           }
         }
+      }
+    }
+  }
+}
+
+// ---- EPI 3: SwiGLU fused into the c_fc / proj GEMM (reference model.py:148-154, 259-261) -----------
+// The weight shadow interleaves u/v partners 16 columns apart (perm=1), so acc[i][2jj] (u) and
+// acc[i][2jj+1] (v) of one lane are gate partners.  Writes the raw pre-activation tile (saved for
+// backward) and the gated activation, both bf16, both as whole-row 16-byte stores via the LDS scratch.
+template <int FMR>
+__device__ __forceinline__ void nt_store_tile_swiglu(const NtArgs& g, f32x4 (&acc)[FMR][4], int m_base, int n_base,
+                                                     int lane, char* scratch) {
+  const int l15 = lane & 15, lg = lane >> 4;
+  f32x4 gu[2], gv[2];
+#pragma unroll
+  for (int jj = 0; jj < 2; ++jj) {
+    const int nb = n_base + jj * 32 + 4 * lg;
+    if (g.gs) {
+      gu[jj] = *reinterpret_cast<const f32x4*>(g.gs + nb) * g.gscale;
+      gv[jj] = *reinterpret_cast<const f32x4*>(g.gs + nb + 16) * g.gscale;
+    } else {
+      gu[jj] = (f32x4){1.f, 1.f, 1.f, 1.f};
+      gv[jj] = gu[jj];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < FMR; ++i) {
+    // pass A: raw uv, 64 columns
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int bytecol = (j * 16 + 4 * lg) * 2;
+      char* dst = scratch + l15 * 128 + (((bytecol >> 4) ^ (l15 & 7)) << 4) + (bytecol & 15);
+      store4<bf16>(reinterpret_cast<bf16*>(dst), acc[i][j]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int idx = lane + 64 * t;
+      const int row = idx >> 3, chunk = idx & 7;
+      const uint4 raw = *reinterpret_cast<const uint4*>(scratch + row * 128 + ((chunk ^ (row & 7)) << 4));
+      const int m = m_base + i * 16 + row;
+      if (m < g.M)
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(g.C) + (size_t)m * g.ldc + n_base + chunk * 8) = raw;
+    }
+    // pass B: gated activation, 32 columns
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const f32x4 u = acc[i][2 * jj] * gu[jj], v = acc[i][2 * jj + 1] * gv[jj];
+      f32x4 x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = u[e] * (v[e] / (1.0f + __expf(-v[e])));
+      const int bytecol = (jj * 16 + 4 * lg) * 2;
+      char* dst = scratch + l15 * 128 + (((bytecol >> 4) ^ (l15 & 7)) << 4) + (bytecol & 15);
+      store4<bf16>(reinterpret_cast<bf16*>(dst), x);
+    }
+    {
+      const int row = lane >> 2, chunk = lane & 3;
+      const uint4 raw = *reinterpret_cast<const uint4*>(scratch + row * 128 + ((chunk ^ (row & 7)) << 4));
+      const int m = m_base + i * 16 + row;
+      if (m < g.M)
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16*>(g.xm) + (size_t)m * g.ld_xm + (n_base >> 1) + chunk * 8) = raw;
+    }
+  }
+}
+
+// ---- EPI 4: per-head cosine normalise + learned scale + head split fused into the q/k/v GEMM --------
+// (reference model.py:104-119, 231-247).  A wave's 64 columns are exactly one head (d = 64).
+template <int FMR>
+__device__ __forceinline__ void nt_store_tile_qknorm(const NtArgs& g, f32x4 (&acc)[FMR][4], int m_base, int n_base,
+                                                     int lane, char* scratch) {
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int part = g.part0 + n_base / g.Cemb;  // 0 = q, 1 = k, 2 = v
+  const int c0 = n_base % g.Cemb, h = c0 >> 6;
+  f32x4 sc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) sc[j] = *reinterpret_cast<const f32x4*>(g.sqk + c0 + j * 16 + 4 * lg) * g.c_q;
+  bf16* outp = reinterpret_cast<bf16*>(part == 0 ? g.qh : (part == 1 ? g.kh : g.vh));
+  float* rn_out = part == 0 ? g.rq : g.rk;
+#pragma unroll
+  for (int i = 0; i < FMR; ++i) {
+    float rn = 1.0f;
+    if (part < 2) {
+      float ss = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        ss += acc[i][j][0] * acc[i][j][0] + acc[i][j][1] * acc[i][j][1] + acc[i][j][2] * acc[i][j][2] +
+              acc[i][j][3] * acc[i][j][3];
+      ss += __shfl_xor(ss, 16, 64);
+      ss += __shfl_xor(ss, 32, 64);
+      rn = 1.0f / sqrtf(ss);
+      const int m = m_base + i * 16 + l15;
+      if (lg == 0 && m < g.M) rn_out[(size_t)m * g.H + h] = rn;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 v = acc[i][j];
+      if (part < 2) v = v * rn * sc[j];
+      const int bytecol = (j * 16 + 4 * lg) * 2;
+      char* dst = scratch + l15 * 128 + (((bytecol >> 4) ^ (l15 & 7)) << 4) + (bytecol & 15);
+      store4<bf16>(reinterpret_cast<bf16*>(dst), v);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int idx = lane + 64 * t;
+      const int row = idx >> 3, chunk = idx & 7;
+      const uint4 raw = *reinterpret_cast<const uint4*>(scratch + row * 128 + ((chunk ^ (row & 7)) << 4));
+      const int m = m_base + i * 16 + row;
+      if (m < g.M) {
+        const int b = m / g.Ttok, tt = m - b * g.Ttok;
+        *reinterpret_cast<uint4*>(outp + (((size_t)b * g.H + h) * g.Ttok + tt) * 64 + chunk * 8) = raw;
       }
     }
   }

@@ -38,7 +38,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 }
 
-// EPI: 0 = generic direct epilogue, 1 = LDS-staged bf16 output, 2 = LDS-staged fp32 output
+// EPI: 0 = generic direct epilogue, 1 = LDS-staged bf16 output, 2 = LDS-staged fp32 output,
+//      3 = fused SwiGLU (bf16), 4 = fused q/k-normalise + head split (bf16)
 template <typename T, int FM, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int tiles_m, int ntiles) {
   using Cfg = PCfg<FM>;
@@ -174,6 +175,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
           nt_store_tile_staged<FM, bf16>(g, acc, m0 + wr * WROWS, n0 + wc * 64, lane, scratch);
         else if constexpr (EPI == 2)
           nt_store_tile_staged<FM, float>(g, acc, m0 + wr * WROWS, n0 + wc * 64, lane, scratch);
+        else if constexpr (EPI == 3)
+          nt_store_tile_swiglu<FM>(g, acc, m0 + wr * WROWS, n0 + wc * 64, lane, scratch);
+        else if constexpr (EPI == 4)
+          nt_store_tile_qknorm<FM>(g, acc, m0 + wr * WROWS, n0 + wc * 64, lane, scratch);
         else
           nt_store_tile<FM>(g, acc, m0 + wr * WROWS, n0 + wc * 64, l15, lg);
       }
@@ -226,6 +231,26 @@ int launch_p(const NtArgs& g, int n_cu, hipStream_t s) {
 }
 
 }  // namespace
+
+static int p_num_cu() {
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int devid = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&devid) != hipSuccess || hipGetDeviceProperties(&prop, devid) != hipSuccess) return 0;
+    n_cu = prop.multiProcessorCount;
+    n_cu -= n_cu % 8;
+    if (n_cu < 8) n_cu = 8;
+  }
+  return n_cu;
+}
+
+// fused-epilogue launches (bf16 operands, 256x256 tiles): epi = 3 (SwiGLU) or 4 (q/k normalise)
+int nvit_gemm_nt_fused_launch(const NtArgs& g, int epi, hipStream_t s) {
+  const int n_cu = p_num_cu();
+  if (n_cu == 0) NVIT_FAIL(NVIT_EINVAL, "gemm_nt: cannot query device properties");
+  return epi == 3 ? launch_p2<bf16, 8, 3>(g, n_cu, s) : launch_p2<bf16, 8, 4>(g, n_cu, s);
+}
 
 // tile_n: 128 or 256
 int nvit_gemm_nt_persistent_launch(int dt, const NtArgs& g, int tile_n, hipStream_t s) {

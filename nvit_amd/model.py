@@ -127,6 +127,8 @@ class _Runtime:
             stack(f"h{i}.o", [blk.att_c_proj])
             stack(f"h{i}.fc", [blk.c_fc], perm=1)
             stack(f"h{i}.p", [blk.mlp_c_proj])
+            # suv in the interleaved (perm=1) column order of the c_fc shadow, for the fused SwiGLU epilogue
+            bent.append((blk.suv.detach().reshape(8 * C, 1), newb(f"h{i}.suv_i", 8 * C), 1, 1, None, 0, 0, 1))
         # classifier head: transposed shadow zero-padded along classes to a multiple of the K stage
         ncls = cfg.num_classes
         Kp = ops.round_up(ncls, bk)
@@ -205,17 +207,26 @@ class _BlockFn(torch.autograd.Function):
         c_q, c_a = 1.0 / cfg.base_scale, 0.05 / cfg.base_scale
         pre = f"h{idx}."
         has_b = bq is not None
-        qkv = ops.gemm_nt(x_lo, sh[pre + "qkv.W"], M, 3 * C, C, out_dtype=td, bias=sh.get(pre + "qkv.b"))
-        qh, kh, vh, rq, rk, o, lse = _attn_part_fwd(rt, impl, qkv, 3 * C, qkv[:, C:], 3 * C, qkv[:, 2 * C:], 3 * C,
-                                                     sqk, c_q, B, T, H, d)
-        del qkv
+        if not has_b and d == 64 and ops.fusable(dt, M, 3 * C, C):
+            # q/k/v projection with the per-head normalise + sqk scale + head split in the GEMM epilogue
+            qh, kh, vh, rq, rk = ops.gemm_nt_qknorm(x_lo, sh[pre + "qkv.W"], M, C, 3, 0, sqk, c_q, B, T, H, d)
+            o, lse = ops.attn_fwd(dt, impl, qh, kh, vh, math.sqrt(d))
+        else:
+            qkv = ops.gemm_nt(x_lo, sh[pre + "qkv.W"], M, 3 * C, C, out_dtype=td, bias=sh.get(pre + "qkv.b"))
+            qh, kh, vh, rq, rk, o, lse = _attn_part_fwd(rt, impl, qkv, 3 * C, qkv[:, C:], 3 * C, qkv[:, 2 * C:],
+                                                         3 * C, sqk, c_q, B, T, H, d)
+            del qkv
         y = ops.gemm_nt(o, sh[pre + "o.W"], M, C, C, out_dtype=torch.float32, bias=sh.get(pre + "o.b"))
         h1, h1_lo = ops.lerp_fwd(dt, x, y, attn_alpha, c_a, want_lo=(dt != F32))
         if dt == F32:
             h1_lo = h1
-        uv = ops.gemm_nt(h1_lo, sh[pre + "fc.W"], M, 8 * C, C, out_dtype=td, bias=sh.get(pre + "fc.b"))
         gscale = math.sqrt(C)
-        xm = ops.swiglu_fwd(dt, uv, suv, gscale, M, 4 * C)
+        if not has_b and ops.fusable(dt, M, 8 * C, C):
+            # c_fc GEMM with suv scale + SwiGLU gate in the epilogue (writes raw uv for backward and x_mlp)
+            uv, xm = ops.gemm_nt_swiglu(h1_lo, sh[pre + "fc.W"], M, 4 * C, C, sh[pre + "suv_i"], gscale)
+        else:
+            uv = ops.gemm_nt(h1_lo, sh[pre + "fc.W"], M, 8 * C, C, out_dtype=td, bias=sh.get(pre + "fc.b"))
+            xm = ops.swiglu_fwd(dt, uv, suv, gscale, M, 4 * C)
         y2 = ops.gemm_nt(xm, sh[pre + "p.W"], M, C, 4 * C, out_dtype=torch.float32, bias=sh.get(pre + "p.b"))
         if with_skip:
             xn, xn_lo = ops.lerp_fwd(dt, h1, y2, mlp_alpha, c_a, skip_x=x, skip=skip_param, want_lo=(dt != F32))
@@ -314,12 +325,22 @@ class _CrossFn(torch.autograd.Function):
             loc_lo, glo_lo = loc, glo
         else:
             loc_lo, glo_lo = ops.cast(loc, dt), ops.cast(glo, dt)
-        q = ops.gemm_nt(loc_lo, sh["x.q.W"], M, C, C, out_dtype=td, bias=sh.get("x.q.b"))
-        kv = ops.gemm_nt(glo_lo, sh["x.kv.W"], M, 2 * C, C, out_dtype=td, bias=sh.get("x.kv.b"))
-        qh, kh, vh, rq, rk, o, lse = _attn_part_fwd(rt, impl, q, C, kv, 2 * C, kv[:, C:], 2 * C, sqk, c_q, B, T, H, d)
-        del q, kv
-        pr = ops.gemm_nt(o, sh["x.proj.W"], M, 2 * C, C, out_dtype=td, bias=sh.get("x.proj.b"))
-        g = ops.swiglu_fwd(dt, pr, None, 1.0, M, C)
+        if not has_b and d == 64 and ops.fusable(dt, M, C, C):
+            bufs = ops.qk_buffers(dt, B, T, H, d, loc.device)
+            ops.gemm_nt_qknorm(loc_lo, sh["x.q.W"], M, C, 1, 0, sqk, c_q, B, T, H, d, bufs)
+            qh, kh, vh, rq, rk = ops.gemm_nt_qknorm(glo_lo, sh["x.kv.W"], M, C, 2, 1, sqk, c_q, B, T, H, d, bufs)
+            o, lse = ops.attn_fwd(dt, impl, qh, kh, vh, math.sqrt(d))
+        else:
+            q = ops.gemm_nt(loc_lo, sh["x.q.W"], M, C, C, out_dtype=td, bias=sh.get("x.q.b"))
+            kv = ops.gemm_nt(glo_lo, sh["x.kv.W"], M, 2 * C, C, out_dtype=td, bias=sh.get("x.kv.b"))
+            qh, kh, vh, rq, rk, o, lse = _attn_part_fwd(rt, impl, q, C, kv, 2 * C, kv[:, C:], 2 * C, sqk, c_q, B, T,
+                                                         H, d)
+            del q, kv
+        if not has_b and ops.fusable(dt, M, 2 * C, C):
+            pr, g = ops.gemm_nt_swiglu(o, sh["x.proj.W"], M, C, C, None, 1.0)
+        else:
+            pr = ops.gemm_nt(o, sh["x.proj.W"], M, 2 * C, C, out_dtype=td, bias=sh.get("x.proj.b"))
+            g = ops.swiglu_fwd(dt, pr, None, 1.0, M, C)
         y = ops.gemm_nt(g, sh["x.out.W"], M, C, C, out_dtype=torch.float32, bias=sh.get("x.out.b"))
         x, x_lo = ops.lerp_fwd(dt, loc, y, attn_alpha, c_a, want_lo=(dt != F32))
         if dt == F32:

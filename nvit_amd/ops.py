@@ -72,6 +72,45 @@ def gemm_nt(A: Tensor, B: Tensor, M: int, N: int, K: int, out: Optional[Tensor] 
     return out
 
 
+FUSE_MIN_ELEMS = 256 * 256 * 64   # below this output size the fused persistent kernel is not worth a launch
+
+
+def fusable(dt: int, M: int, N: int, K: int) -> bool:
+    """True when the fused-epilogue persistent GEMM (nvit_gemm_nt_swiglu / _qknorm) can and should be used."""
+    return bool(_lib.load().nvit_gemm_nt_fusable(dt, M, N, K)) and M * N >= FUSE_MIN_ELEMS
+
+
+def gemm_nt_swiglu(A: Tensor, B: Tensor, M: int, F: int, K: int, gs: Optional[Tensor], gscale: float):
+    """uv [M,2F] (raw, interleaved) and xm [M,F] = swiglu(uv) in one launch (bf16)."""
+    _chk_dev(A, B)
+    uv = torch.empty((M, 2 * F), device=A.device, dtype=torch.bfloat16)
+    xm = torch.empty((M, F), device=A.device, dtype=torch.bfloat16)
+    check(_lib.load().nvit_gemm_nt_swiglu(dt_of(A), _p(A), A.stride(0), _p(B), B.stride(0), _p(uv), _p(xm), M, F, K,
+                                          _p(gs), gscale, _s()), "nvit_gemm_nt_swiglu")
+    return uv, xm
+
+
+def qk_buffers(dt: int, B: int, T: int, H: int, d: int, device):
+    td = tdtype(dt)
+    qh = torch.empty((B, H, T, d), device=device, dtype=td)
+    return (qh, torch.empty_like(qh), torch.empty_like(qh),
+            torch.empty((B * T, H), device=device, dtype=torch.float32),
+            torch.empty((B * T, H), device=device, dtype=torch.float32))
+
+
+def gemm_nt_qknorm(A: Tensor, B: Tensor, M: int, K: int, nparts: int, part0: int, sqk: Tensor, c_q: float, Bsz: int,
+                   T: int, H: int, d: int, bufs=None):
+    """q/k/v projection(s) with the per-head normalise, sqk scale and head split fused (bf16, d=64)."""
+    _chk_dev(A, B)
+    if bufs is None:
+        bufs = qk_buffers(dt_of(A), Bsz, T, H, d, A.device)
+    qh, kh, vh, rq, rk = bufs
+    check(_lib.load().nvit_gemm_nt_qknorm(dt_of(A), _p(A), A.stride(0), _p(B), B.stride(0), M, K, nparts, part0,
+                                          _p(sqk), c_q, _p(qh), _p(kh), _p(vh), _p(rq), _p(rk), T, H, d, _s()),
+          "nvit_gemm_nt_qknorm")
+    return bufs
+
+
 _ws_cache = {}
 
 

@@ -137,3 +137,41 @@ def test_state_dict_keys_and_no_cpu_fallback():
     m = ViT(cfg)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 3, 32, 32))
+
+
+def test_bf16_fused_epilogues_match_unfused_and_oracle():
+    """A config large enough to take the fused-epilogue persistent GEMMs (q/k normalise, SwiGLU), the
+    persistent 256x256 NT/TN kernels and the MFMA attention: against the fp32 oracle and against the
+    same model with the fusions switched off."""
+    from nvit_amd import ops
+    cfg = named_config("mini", n_embd=256, n_head=4, num_classes=16)
+    batch = 112
+    X, y = synthetic_batch(cfg, batch)
+    p, logits_ref, loss_ref, _ = oracle_run(cfg, X, y, True)
+
+    def run(fuse_min):
+        old = ops.FUSE_MIN_ELEMS
+        ops.FUSE_MIN_ELEMS = fuse_min
+        try:
+            m = build(cfg, "bf16", True).train()
+            logits, aux = m(X.cuda())
+            torch.nn.functional.cross_entropy(logits, y.cuda()).backward()
+            return logits.detach().cpu(), {n: q.grad.cpu() for n, q in m.named_parameters() if q.grad is not None}
+        finally:
+            ops.FUSE_MIN_ELEMS = old
+
+    T = (cfg.image_size // cfg.local_patch_size) ** 2
+    assert ops.fusable(1, batch * T, 3 * cfg.n_embd, cfg.n_embd), "test config no longer reaches the fused path"
+    lf, gf = run(ops.FUSE_MIN_ELEMS)
+    lu, gu = run(1 << 62)
+    e_or = (lf - logits_ref).abs().max().item()
+    e_fu = (lf - lu).abs().max().item()
+    print(f"[fused] max|dlogit| vs fp32 oracle {e_or:.3e}, fused vs unfused {e_fu:.3e}")
+    assert e_or < 5e-3 and e_fu < 2e-3
+    for n in gf:
+        a, b, r = gf[n].flatten().double(), gu[n].flatten().double(), p[n].grad.flatten().double()
+        if r.norm() < 1e-12:
+            continue
+        cos_u = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+        cos_r = (a @ r / (a.norm() * r.norm() + 1e-30)).item()
+        assert cos_u > 0.995 and cos_r > 0.98, (n, cos_u, cos_r)

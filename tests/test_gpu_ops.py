@@ -306,3 +306,42 @@ def test_small_reductions_and_cast():
     s = rnd(52, seed=4)
     o2 = ops.scale_cols(a.to(d), s.to(d), 2.0, 300, 52, torch.empty(300, 52, device=d))
     assert (o2.cpu() - a * s * 2.0).abs().max().item() < 1e-5
+
+
+def test_fused_gemm_swiglu_and_qknorm_match_unfused():
+    """Fused-epilogue persistent GEMMs (bf16) against the unfused kernel sequence on the same inputs."""
+    ops = ops_()
+    from nvit_amd._lib import BF16
+    d_ = dev()
+    # SwiGLU: M x (2F) with interleaved shadow
+    M, F, K = 6000, 512, 256
+    A = rnd(M, K, seed=1).bfloat16().to(d_)
+    W = (rnd(2 * F, K, seed=2) * 0.05).bfloat16().to(d_)
+    gs = (rnd(2 * F, seed=3, scale=0.1) + 1).to(d_)
+    assert ops.fusable(BF16, M, 2 * F, K)
+    uv, xm = ops.gemm_nt_swiglu(A, W, M, F, K, gs, 3.0)
+    uv_ref = ops.gemm_nt(A, W, M, 2 * F, K, out_dtype=torch.bfloat16)
+    assert torch.equal(uv, uv_ref)
+    # reference gate in fp32 from the fp32 accumulators (uv_ref is rounded, so compare at bf16 tolerance)
+    acc = A.float() @ W.float().t()
+    z = acc * (gs * 3.0)
+    zz = z.reshape(M, F // 16, 2, 16)
+    want = (zz[:, :, 0] * (zz[:, :, 1] * torch.sigmoid(zz[:, :, 1]))).reshape(M, F)
+    assert (xm.float() - want).abs().max().item() < 2e-2 * max(1.0, want.abs().max().item())
+    # q/k normalise: 3 stacked projections, C = 256 (H = 4, d = 64), T = 50
+    B, T, H, d = 12, 50, 4, 64
+    C = H * d
+    M = B * T
+    X = rnd(M, C, seed=4).bfloat16().to(d_)
+    Wqkv = (rnd(3 * C, C, seed=5) * 0.05).bfloat16().to(d_)
+    sqk = (rnd(C, seed=6, scale=0.003) + 1 / 32).to(d_)
+    qh, kh, vh, rq, rk = ops.gemm_nt_qknorm(X, Wqkv, M, C, 3, 0, sqk, 32.0, B, T, H, d)
+    acc = (X.float() @ Wqkv.float().t()).reshape(B, T, 3, H, d).permute(2, 0, 3, 1, 4)   # [3,B,H,T,d]
+    s = (sqk * 32.0).reshape(1, H, 1, d)
+    nq = acc[0] / acc[0].norm(dim=-1, keepdim=True) * s
+    nk = acc[1] / acc[1].norm(dim=-1, keepdim=True) * s
+    assert (qh.float() - nq).abs().max().item() < 1e-2
+    assert (kh.float() - nk).abs().max().item() < 1e-2
+    assert (vh.float() - acc[2]).abs().max().item() < 2e-2 * acc[2].abs().max().item()
+    rq_ref = (1.0 / acc[0].norm(dim=-1)).permute(0, 2, 1).reshape(M, H)
+    assert (rq - rq_ref).abs().max().item() < 1e-3 * rq_ref.abs().max().item()
