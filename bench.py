@@ -50,6 +50,19 @@ def cpu_baseline(cfg_name: str, sample_batch: int, threads: int):
                       f"{dt:.1f} s"}
 
 
+def pmc_traffic():
+    """HBM-side bytes per gemm_nt launch from the committed rocprofv3 PMC summary of this same command
+    (profiles/*_pmc.json, made by tools/summarize_profile.py; PMC counters cannot be read inside the run)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,7 +153,7 @@ def main() -> None:
             "step_mfma_frac": round(value * gf / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
             "roofline": {"bound": "mfma", "kernel": "gemm_nt (persistent 256x256 tile, bf16 v_mfma_f32_16x16x32, LDS-DMA ring)",
                          "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
                          "launches": g["launches"], "avg_launch_ms": round(g["ms"] / max(1, g["launches"]), 4)},
             "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]},
         }

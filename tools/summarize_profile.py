@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 CSV output (gpurun_out/, scratch) into the small summaries committed under profiles/.
+
+  python tools/summarize_profile.py <round-tag> --trace gpurun_out/prof_x --fetch gpurun_out/pmc_fetch \
+         --write gpurun_out/pmc_write [--cmd "python3 bench.py ..."]
+
+Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats summary, verbatim columns, top 40),
+profiles/<tag>_pmc.csv (per-kernel average FETCH_SIZE / WRITE_SIZE per launch) and profiles/<tag>_pmc.json
+(gemm_nt family: HBM-side traffic per launch, gfx950 correction applied: FETCH_SIZE counts 64 B per 128-B
+request on wide coalesced reads -> x2; both counters are in KiB; MI355X_MICROARCH.md §HBM)."""
+import argparse, collections, csv, glob, json, os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    for key in ("gemm_nt_persistent", "gemm_tn_persistent", "gemm_nt_kernel", "gemm_tn_kernel", "attn_fwd_mfma",
+                "attn_bwd_dq_mfma", "attn_bwd_dkv_mfma", "attn_delta", "lerp_fwd", "lerp_bwd", "qknorm_fwd",
+                "qknorm_bwd", "swiglu_fwd", "swiglu_bwd", "colsum_reduce", "colsum_kernel", "slab_reduce", "renorm",
+                "shadow", "im2col", "pool", "recon", "cast_kernel", "scale_cols", "FusedAdam", "multi_tensor",
+                "elementwise", "rocclr", "reduce_kernel", "softmax", "nll_loss"):
+        if key in name:
+            if key.startswith("gemm_nt_persistent"):
+                import re
+                m = re.search(r"Li(\d)ELi(\d)E", name)
+                return f"gemm_nt_persistent<FM={m.group(1)},EPI={m.group(2)}>" if m else key
+            return key
+    return name[:60]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("--trace")
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--cmd", default="")
+    a = ap.parse_args()
+    out = os.path.join(ROOT, "profiles")
+    os.makedirs(out, exist_ok=True)
+    if a.trace:
+        f = glob.glob(os.path.join(a.trace, "*", "*kernel_stats.csv"))[0]
+        rows = list(csv.DictReader(open(f)))
+        with open(os.path.join(out, f"{a.tag}_kernel_stats.csv"), "w") as w:
+            w.write(f"# rocprofv3 --kernel-trace --stats -- {a.cmd}\n")
+            cw = csv.writer(w)
+            cw.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
+            for r in rows[:40]:
+                cw.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                             r["MinNs"], r["MaxNs"]])
+    pm = {}
+    for kind, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
+        if not d:
+            continue
+        f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+        agg = collections.defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            agg[k][0] += 1
+            agg[k][1] += float(r["Counter_Value"])
+        pm[kind] = agg
+    if pm:
+        names = sorted(set().union(*[set(v) for v in pm.values()]))
+        with open(os.path.join(out, f"{a.tag}_pmc.csv"), "w") as w:
+            w.write(f"# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- {a.cmd}; values in KiB per launch (raw)\n")
+            cw = csv.writer(w)
+            cw.writerow(["Kernel", "Launches", "FETCH_SIZE_KiB_avg", "WRITE_SIZE_KiB_avg"])
+            for n in names:
+                fe = pm.get("FETCH_SIZE", {}).get(n, [0, 0.0])
+                wr = pm.get("WRITE_SIZE", {}).get(n, [0, 0.0])
+                cw.writerow([n, max(fe[0], wr[0]), round(fe[1] / max(1, fe[0]), 1), round(wr[1] / max(1, wr[0]), 1)])
+        fam = [n for n in names if n.startswith("gemm_nt")]
+        nl = sum(pm["FETCH_SIZE"][n][0] for n in fam) if "FETCH_SIZE" in pm else 0
+        fetch = sum(pm["FETCH_SIZE"][n][1] for n in fam) if "FETCH_SIZE" in pm else 0.0
+        write = sum(pm["WRITE_SIZE"][n][1] for n in fam) if "WRITE_SIZE" in pm else 0.0
+        js = {"family": "gemm_nt", "launches": nl, "fetch_bytes_per_launch_corrected": 2.0 * fetch * 1024 / max(1, nl),
+              "write_bytes_per_launch": write * 1024 / max(1, nl),
+              "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024 / max(1, nl),
+              "note": "L2<->fabric bytes (Infinity-Cache hits are included by these counters); FETCH_SIZE x2 per the gfx950 correction",
+              "cmd": a.cmd}
+        json.dump(js, open(os.path.join(out, f"{a.tag}_pmc.json"), "w"), indent=1)
+        print(js)
+
+
+if __name__ == "__main__":
+    main()
