@@ -32,6 +32,11 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
+// raw v_exp_f32 (no denormal range fix-up: arguments here are <= 0 after max subtraction, or bounded
+// by the saved log-sum-exp in the backward kernels; results below 2^-126 flush to 0, which is the
+// correct limit for a softmax weight)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
 
 __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c) {
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
       mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
       mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
       const float mn = fmaxf(m_[f], mt);
-      const float corr = exp2f((m_[f] - mn) * c2);
+      const float corr = fast_exp2((m_[f] - mn) * c2);
       m_[f] = mn;
       const float mc = mn * c2;
       float rs = 0.f;
@@ -170,7 +175,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(s[kf][f][r] * c2 - mc);
+          const float p = fast_exp2(s[kf][f][r] * c2 - mc);
           s[kf][f][r] = p;
           rs += p;
         }
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __res
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const bool valid = (kbase_i + kf * 16 + lg * 4 + r) < Tk;
-            const float p = valid ? exp2f(z[r] * c2 - lse2[f]) : 0.f;
+            const float p = valid ? fast_exp2(z[r] * c2 - lse2[f]) : 0.f;
             ds_[kk][f][r] = p * (w[r] - dl[f]) * scale;
           }
         }
@@ -403,7 +408,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16* __re
           w = mfma16(g1, vf_[f][1], w);  // dP[q][key]
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float p = exp2f(z[r] * c2 - l4[r]);
+            const float p = fast_exp2(z[r] * c2 - l4[r]);
             p_[qq][f][r] = p;
             ds_[qq][f][r] = p * (w[r] - d4[r]) * scale;
           }
