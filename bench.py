@@ -72,6 +72,9 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for rehearsals")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: all ranks use cuda:0 (needs --backend gloo); not a valid benchmark")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     args = ap.parse_args()
 
@@ -87,10 +90,15 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1:
         assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend, init_method="env://")
 
     cfg = named_config(args.config)
     model = ViT(cfg)
@@ -144,7 +152,7 @@ def main() -> None:
             "metric": "images/sec (train step) nViT-B/16 224px", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision,
-            "data": "synthetic",
+            "data": "synthetic" if not args.share_gpu else "synthetic (REHEARSAL: ranks share one GPU, not a benchmark)",
             "config": {"workload": f"nViT-{args.config} {cfg.image_size}px patches {cfg.local_patch_size}/"
                                    f"{cfg.global_patch_size} T={T} C={cfg.n_embd} L={cfg.n_layer} H={cfg.n_head}, "
                                    f"full train step (fwd+bwd+clip+AdamW+renorm), synthetic images, formula weights",
