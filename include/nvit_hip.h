@@ -174,6 +174,14 @@ int nvit_attn_bwd(int dt, int impl, const void* dout, const void* qh, const void
                   const float* lse, float scale, void* dqh, void* dkh, void* dvh, float* delta, int B, int H,
                   int Tq, int Tk, int d, void* stream);
 
+/* nvit_attn_bwd_qknorm: MFMA attention backward (bf16, d=64) with nvit_qknorm_bwd fused into the epilogues:
+ * writes token-major dq/dk/dv (type bf16, row stride ld elements, head h at column h*64) and the partial sums
+ * part_q [B*ceil(Tq/128), C], part_k [B*ceil(Tk/128), C] of d/d(sqk*c_q) (reduce with nvit_colsum_reduce). */
+int nvit_attn_bwd_qknorm(int dt, const void* dout, const void* qh, const void* kh, const void* vh, const void* o,
+                         const float* lse, float scale, const float* rq, const float* rk, const float* sqk, float c_q,
+                         void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q, float* part_k, float* delta, int B, int H,
+                         int Tq, int Tk, int d, void* stream);
+
 /* ---- patch embedding / head / reconstruction -------------------------------------------
  * nvit_im2col: A_l [M, ch*Pl*Pl] and A_g [M, ch*Pg*Pg] (type dt, column order (c,ph,pw)) from
  * img fp32 [B,ch,S,S]; global windows are reflect-padded by (Pg-Pl)/2 and strided by Pl

@@ -45,6 +45,8 @@ SIGNATURES = {
     "nvit_scale_cols": [_vp, _i, _vp, _f, _vp, _i, _i, _i, _i, _vp],
     "nvit_attn_fwd": [_i, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_attn_bwd": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "nvit_attn_bwd_qknorm": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp, _vp,
+                             _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_im2col": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_pool_ln_fwd": [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "nvit_pool_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -215,12 +215,80 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
   }
 }
 
+// Fused backward of  x_hat = (sqk*c_q) * x/||x||  (reference model.py:108-112) in the epilogue of the attention
+// backward kernels: g = dL/dx_hat in the accumulator layout (row = row0 + 16f + l15, d = 16df + 4lg + r).
+// Writes dL/dx (bf16, token-major) and this workgroup's partial sums of dL/d(sqk*c_q) for its head.
+struct QkFuse {
+  const float* rn;    // [B*T, H] 1/||x|| saved by the forward
+  const float* sqk;   // [C]
+  float c_q;
+  bf16* out;          // token-major gradient of the projection output: out[(b*T + row)*ld + h*64 + d]
+  bf16* out_v;        // (dk/dv kernel only) same for the value projection
+  int ld;
+  float* part;        // [B * gridDim.x, C]
+};
+
+__device__ __forceinline__ void qk_bwd_epilogue(f32x4 (&g)[4][2], const bf16* xh_bh, const QkFuse& fu, int row0, int T,
+                                                int H, int b, int h, int lane, int wid, float* red) {
+  const int l15 = lane & 15, lg = lane >> 4;
+  f32x4 s[4], sinv[4], ds[4];
+#pragma unroll
+  for (int df = 0; df < 4; ++df) {
+    s[df] = *reinterpret_cast<const f32x4*>(fu.sqk + h * 64 + df * 16 + 4 * lg) * fu.c_q;
+    ds[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sinv[df][e] = s[df][e] != 0.f ? 1.0f / s[df][e] : 0.f;
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int row = row0 + 16 * f + l15;
+    const bool valid = row < T;
+    const int rc = valid ? row : T - 1;
+    f32x4 n[4], sg[4];
+    float dot = 0.f;
+#pragma unroll
+    for (int df = 0; df < 4; ++df) {
+      n[df] = load4<bf16>(xh_bh + (size_t)rc * 64 + df * 16 + 4 * lg) * sinv[df];
+      if (valid) ds[df] += g[df][f] * n[df];
+      sg[df] = g[df][f] * s[df];
+      dot += sg[df][0] * n[df][0] + sg[df][1] * n[df][1] + sg[df][2] * n[df][2] + sg[df][3] * n[df][3];
+    }
+    dot += __shfl_xor(dot, 16, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    if (valid) {
+      const size_t m = (size_t)b * T + row;
+      const float rn = fu.rn[m * H + h];
+      bf16* op = fu.out + m * fu.ld + h * 64 + 4 * lg;
+#pragma unroll
+      for (int df = 0; df < 4; ++df) store4<bf16>(op + df * 16, (sg[df] - n[df] * dot) * rn);
+    }
+  }
+  // column sums over this workgroup's 128 rows: 16 lanes (l15) -> 4 waves -> one partial row
+#pragma unroll
+  for (int df = 0; df < 4; ++df)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = ds[df][e];
+      v += __shfl_xor(v, 1, 64);
+      v += __shfl_xor(v, 2, 64);
+      v += __shfl_xor(v, 4, 64);
+      v += __shfl_xor(v, 8, 64);
+      if (l15 == 0) red[wid * 64 + df * 16 + 4 * lg + e] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const float t = red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x];
+    fu.part[((size_t)b * gridDim.x + blockIdx.x) * (H * 64) + h * 64 + threadIdx.x] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ dQ
+template <bool FUSE>
 __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
                                                                 const bf16* __restrict__ kh, const bf16* __restrict__ vh,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta, float scale,
-                                                                bf16* __restrict__ dqh, int H, int Tq, int Tk) {
+                                                                bf16* __restrict__ dqh, int H, int Tq, int Tk, QkFuse fu) {
   __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -309,24 +377,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __res
     __syncthreads();
     cur ^= 1;
   }
+  if constexpr (FUSE) {
+    qk_bwd_epilogue(dq, qh + (size_t)bh * Tq * D, fu, q0, Tq, H, b, h, lane, wid, reinterpret_cast<float*>(&lds[0][0][0]));
+  } else {
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int q = q0 + 16 * f + l15;
-    if (q < Tq) {
-      bf16* op = dqh + ((size_t)bh * Tq + q) * D + 4 * lg;
+    for (int f = 0; f < 2; ++f) {
+      const int q = q0 + 16 * f + l15;
+      if (q < Tq) {
+        bf16* op = dqh + ((size_t)bh * Tq + q) * D + 4 * lg;
 #pragma unroll
-      for (int df = 0; df < 4; ++df) store4<bf16>(op + df * 16, dq[df][f]);
+        for (int df = 0; df < 4; ++df) store4<bf16>(op + df * 16, dq[df][f]);
+      }
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
+template <bool FUSE>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
                                                                  const bf16* __restrict__ kh, const bf16* __restrict__ vh,
                                                                  const float* __restrict__ lse,
                                                                  const float* __restrict__ delta, float scale,
                                                                  bf16* __restrict__ dkh, bf16* __restrict__ dvh, int H,
-                                                                 int Tq, int Tk) {
+                                                                 int Tq, int Tk, QkFuse fu) {
   __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];  // [buf][Q|dO]
   __shared__ __attribute__((aligned(16))) float stat[2][2][TKV];       // [buf][lse2|delta]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -440,16 +513,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16* __re
     __syncthreads();
     cur ^= 1;
   }
+  if constexpr (FUSE) {
 #pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const int k = k0 + 16 * f + l15;
-    if (k < Tk) {
-      bf16* kp = dkh + ((size_t)bh * Tk + k) * D + 4 * lg;
-      bf16* vp = dvh + ((size_t)bh * Tk + k) * D + 4 * lg;
+    for (int f = 0; f < 2; ++f) {
+      const int k = k0 + 16 * f + l15;
+      if (k < Tk) {
+        bf16* vp = fu.out_v + ((size_t)b * Tk + k) * fu.ld + h * 64 + 4 * lg;
 #pragma unroll
-      for (int df = 0; df < 4; ++df) {
-        store4<bf16>(kp + df * 16, dk[df][f]);
-        store4<bf16>(vp + df * 16, dv[df][f]);
+        for (int df = 0; df < 4; ++df) store4<bf16>(vp + df * 16, dv[df][f]);
+      }
+    }
+    qk_bwd_epilogue(dk, kh + (size_t)bh * Tk * D, fu, k0, Tk, H, b, h, lane, wid, reinterpret_cast<float*>(&lds[0][0][0]));
+  } else {
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int k = k0 + 16 * f + l15;
+      if (k < Tk) {
+        bf16* kp = dkh + ((size_t)bh * Tk + k) * D + 4 * lg;
+        bf16* vp = dvh + ((size_t)bh * Tk + k) * D + 4 * lg;
+#pragma unroll
+        for (int df = 0; df < 4; ++df) {
+          store4<bf16>(kp + df * 16, dk[df][f]);
+          store4<bf16>(vp + df * 16, dv[df][f]);
+        }
       }
     }
   }
@@ -472,11 +558,33 @@ int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const v
                        int d, hipStream_t s) {
   NVIT_REQUIRE(d == 64, "attn_bwd: the MFMA kernel supports head dim 64 only (got %d)", d);
   dim3 gq(cdiv(Tq, 128), B * H), gk(cdiv(Tk, 128), B * H);
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel, gq, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh, (const bf16*)kh,
-                     (const bf16*)vh, lse, delta, scale, (bf16*)dqh, H, Tq, Tk);
+  QkFuse none{};
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, gq, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
+                     (const bf16*)kh, (const bf16*)vh, lse, delta, scale, (bf16*)dqh, H, Tq, Tk, none);
   NVIT_CHECK_LAUNCH("attn_bwd_dq_mfma");
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh, (const bf16*)kh,
-                     (const bf16*)vh, lse, delta, scale, (bf16*)dkh, (bf16*)dvh, H, Tq, Tk);
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
+                     (const bf16*)kh, (const bf16*)vh, lse, delta, scale, (bf16*)dkh, (bf16*)dvh, H, Tq, Tk, none);
   NVIT_CHECK_LAUNCH("attn_bwd_dkv_mfma");
+  return NVIT_OK;
+}
+
+// attention backward with the q/k-normalise backward fused into the epilogues: writes token-major dq/dk/dv
+// (row stride ld) and the partial sums part_q [B*ceil(Tq/128), C], part_k [B*ceil(Tk/128), C].
+int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, const void* vh, const float* lse,
+                             const float* delta, float scale, const float* rq, const float* rk, const float* sqk,
+                             float c_q, void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q, float* part_k, int B,
+                             int H, int Tq, int Tk, int d, hipStream_t s) {
+  NVIT_REQUIRE(d == 64, "attn_bwd: the MFMA kernel supports head dim 64 only (got %d)", d);
+  NVIT_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0, "attn_bwd: leading dims must be multiples of 4");
+  dim3 gq(cdiv(Tq, 128), B * H), gk(cdiv(Tk, 128), B * H);
+  QkFuse fq{rq, sqk, c_q, (bf16*)dq, nullptr, ldq, part_q};
+  QkFuse fk{rk, sqk, c_q, (bf16*)dk, (bf16*)dv, ldkv, part_k};
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, gq, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
+                     (const bf16*)kh, (const bf16*)vh, lse, delta, scale, (bf16*)nullptr, H, Tq, Tk, fq);
+  NVIT_CHECK_LAUNCH("attn_bwd_dq_mfma_fused");
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
+                     (const bf16*)kh, (const bf16*)vh, lse, delta, scale, (bf16*)nullptr, (bf16*)nullptr, H, Tq, Tk,
+                     fk);
+  NVIT_CHECK_LAUNCH("attn_bwd_dkv_mfma_fused");
   return NVIT_OK;
 }

@@ -197,6 +197,11 @@ int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const v
                        const float* delta, float scale, void* dqh, void* dkh, void* dvh, int B, int H, int Tq, int Tk,
                        int d, hipStream_t s);
 
+int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, const void* vh, const float* lse,
+                             const float* delta, float scale, const float* rq, const float* rk, const float* sqk,
+                             float c_q, void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q, float* part_k, int B,
+                             int H, int Tq, int Tk, int d, hipStream_t s);
+
 extern "C" int nvit_attn_fwd(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, void* o,
                              float* lse, int B, int H, int Tq, int Tk, int d, void* stream) {
   NVIT_REQUIRE(d == 32 || d == 64, "attn_fwd: head dim %d unsupported (32 or 64)", d);
@@ -249,4 +254,21 @@ extern "C" int nvit_attn_bwd(int dt, int impl, const void* dout, const void* qh,
 #undef L
   NVIT_CHECK_LAUNCH("attn_bwd_ref");
   return NVIT_OK;
+}
+
+// MFMA attention backward (bf16, d = 64) with the q/k-normalise backward fused into the epilogues.
+extern "C" int nvit_attn_bwd_qknorm(int dt, const void* dout, const void* qh, const void* kh, const void* vh,
+                                    const void* o, const float* lse, float scale, const float* rq, const float* rk,
+                                    const float* sqk, float c_q, void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q,
+                                    float* part_k, float* delta, int B, int H, int Tq, int Tk, int d, void* stream) {
+  NVIT_REQUIRE(dt == NVIT_BF16 && d == 64, "attn_bwd_qknorm: needs bf16 and head dim 64");
+  NVIT_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "attn_bwd_qknorm: empty problem");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(NVIT_KID_ATTN_BWD, 10.0 * B * H * (double)Tq * Tk * d, 0.0, s);
+  const long long total = (long long)B * Tq * ((H * d) / 8);
+  hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const bf16*)dout,
+                     (const bf16*)o, delta, B, H, Tq, d);
+  NVIT_CHECK_LAUNCH("attn_delta");
+  return nvit_attn_bwd_mfma_fused(dout, qh, kh, vh, lse, delta, scale, rq, rk, sqk, c_q, dq, ldq, dk, dv, ldkv, part_q,
+                                  part_k, B, H, Tq, Tk, d, s);
 }

@@ -289,11 +289,18 @@ class _BlockFn(torch.autograd.Function):
         g_wo = ops.gemm_tn(dy_lo, o, torch.empty((C, C), device=x.device, dtype=torch.float32), M, C, C)
         g_bo = _bias_grad(dy_lo, M, C) if ctx.has_b else None
         del dy_lo
-        dqh, dkh, dvh = ops.attn_bwd(dt, impl, do, qh, kh, vh, o, lse, math.sqrt(d))
         dqkv = torch.empty((M, 3 * C), device=x.device, dtype=td)
-        part_sqk = ops.qknorm_bwd(dt, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q, dqkv, 3 * C, dqkv[:, C:], 3 * C,
-                                  dqkv[:, 2 * C:], 3 * C, B, T, H, d)
-        d_sqk = _param_grad_scaled(part_sqk, sqk, c_q)
+        if impl == 1 and d == 64 and dt != F32:
+            # attention backward with the q/k-normalise backward fused into its epilogues
+            part_q, part_k = ops.attn_bwd_qknorm(do, qh, kh, vh, o, lse, math.sqrt(d), rq, rk, sqk, c_q, dqkv, 3 * C,
+                                                 dqkv[:, C:], dqkv[:, 2 * C:], 3 * C)
+            d_sqk = _param_grad_scaled(part_q, sqk, c_q)
+            ops.colsum_reduce(part_k, d_sqk, True, kind=0, scale=c_q)
+        else:
+            dqh, dkh, dvh = ops.attn_bwd(dt, impl, do, qh, kh, vh, o, lse, math.sqrt(d))
+            part_sqk = ops.qknorm_bwd(dt, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q, dqkv, 3 * C, dqkv[:, C:], 3 * C,
+                                      dqkv[:, 2 * C:], 3 * C, B, T, H, d)
+            d_sqk = _param_grad_scaled(part_sqk, sqk, c_q)
         ops.gemm_nt(dqkv, sh[pre + "qkv.Wt"], M, C, 3 * C, out=dx, accumulate=True)
         g_qkv = ops.gemm_tn(dqkv, x_lo, torch.empty((3 * C, C), device=x.device, dtype=torch.float32), M, 3 * C, C)
         g_bqkv = _bias_grad(dqkv, M, 3 * C) if ctx.has_b else None
@@ -371,12 +378,18 @@ class _CrossFn(torch.autograd.Function):
         do = ops.gemm_nt(dpr, sh["x.proj.Wt"], M, C, 2 * C, out_dtype=td)
         g_wproj = ops.gemm_tn(dpr, o, torch.empty((2 * C, C), device=dev, dtype=torch.float32), M, 2 * C, C, perm=1)
         g_bproj = _bias_grad(dpr, M, 2 * C, perm=1) if ctx.has_b else None
-        dqh, dkh, dvh = ops.attn_bwd(dt, impl, do, qh, kh, vh, o, lse, math.sqrt(d))
         dq = torch.empty((M, C), device=dev, dtype=td)
         dkv = torch.empty((M, 2 * C), device=dev, dtype=td)
-        part_sqk = ops.qknorm_bwd(dt, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q, dq, C, dkv, 2 * C, dkv[:, C:], 2 * C,
-                                  B, T, H, d)
-        d_sqk = _param_grad_scaled(part_sqk, sqk, c_q)
+        if impl == 1 and d == 64 and dt != F32:
+            part_q, part_k = ops.attn_bwd_qknorm(do, qh, kh, vh, o, lse, math.sqrt(d), rq, rk, sqk, c_q, dq, C, dkv,
+                                                 dkv[:, C:], 2 * C)
+            d_sqk = _param_grad_scaled(part_q, sqk, c_q)
+            ops.colsum_reduce(part_k, d_sqk, True, kind=0, scale=c_q)
+        else:
+            dqh, dkh, dvh = ops.attn_bwd(dt, impl, do, qh, kh, vh, o, lse, math.sqrt(d))
+            part_sqk = ops.qknorm_bwd(dt, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q, dq, C, dkv, 2 * C, dkv[:, C:],
+                                      2 * C, B, T, H, d)
+            d_sqk = _param_grad_scaled(part_sqk, sqk, c_q)
         ops.gemm_nt(dq, sh["x.q.Wt"], M, C, C, out=dloc, accumulate=True)
         dglo = ops.gemm_nt(dkv, sh["x.kv.Wt"], M, C, 2 * C, out_dtype=torch.float32)
         g_wq = ops.gemm_tn(dq, loc_lo, torch.empty((C, C), device=dev, dtype=torch.float32), M, C, C)

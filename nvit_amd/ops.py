@@ -301,6 +301,23 @@ def attn_bwd(dt: int, impl: int, dout: Tensor, qh: Tensor, kh: Tensor, vh: Tenso
     return dqh, dkh, dvh
 
 
+def attn_bwd_qknorm(dout: Tensor, qh: Tensor, kh: Tensor, vh: Tensor, o: Tensor, lse: Tensor, scale: float,
+                    rq: Tensor, rk: Tensor, sqk: Tensor, c_q: float, dq: Tensor, ldq: int, dk: Tensor, dv: Tensor,
+                    ldkv: int):
+    """MFMA attention backward + q/k-normalise backward in one pass (bf16, d=64).
+    Writes dq/dk/dv token-major; returns the partial sums (part_q, part_k) of d/d(sqk*c_q)."""
+    B, H, Tq, d = qh.shape
+    Tk = kh.shape[2]
+    dev = qh.device
+    part_q = torch.empty((B * math.ceil(Tq / 128), H * d), device=dev, dtype=torch.float32)
+    part_k = torch.empty((B * math.ceil(Tk / 128), H * d), device=dev, dtype=torch.float32)
+    delta = torch.empty((B, H, Tq), device=dev, dtype=torch.float32)
+    check(_lib.load().nvit_attn_bwd_qknorm(BF16, _p(dout), _p(qh), _p(kh), _p(vh), _p(o), _p(lse), scale, _p(rq),
+                                           _p(rk), _p(sqk), c_q, _p(dq), ldq, _p(dk), _p(dv), ldkv, _p(part_q),
+                                           _p(part_k), _p(delta), B, H, Tq, Tk, d, _s()), "nvit_attn_bwd_qknorm")
+    return part_q, part_k
+
+
 # ----------------------------------------------------------------------------- embed / head
 def im2col(dt: int, img: Tensor, Pl: int, Pg: int):
     B, ch, S, _ = img.shape
