@@ -58,6 +58,14 @@ def named_config(name: str, **over) -> ViTConfig:
                           local_patch_size=16, global_patch_size=32),
         # small parity configs with head dim 64 and a ragged token count
         "mini": dict(image_size=56, n_embd=128, n_layer=2, n_head=2, num_classes=16),
+        # C5-style parity configs: Kohonen head on (nodes per map must be a perfect square)
+        "micro_k": dict(image_size=32, n_embd=64, n_layer=2, n_head=2, num_classes=100, bias=True, dropout=0.15,
+                        use_kohonen=True, kohonen_nodes=128, kohonen_alpha=0.02),
+        "mini_k": dict(image_size=56, n_embd=128, n_layer=2, n_head=2, num_classes=16, use_kohonen=True,
+                       kohonen_nodes=32, kohonen_alpha=0.05, reconstruction_weight=0.5),
+        # C5: nViT-Base + Kohonen head (512 nodes = 2 maps of 16x16)
+        "base_k": dict(image_size=224, n_embd=768, n_layer=12, n_head=12, num_classes=1000, use_kohonen=True,
+                       kohonen_nodes=512),
     }
     kw = dict(common)
     kw.update(table[name])

@@ -93,6 +93,12 @@ def param_shapes(cfg) -> Dict[str, Tuple[int, ...]]:
             s[p + "mlp_c_proj.bias"] = (C,)
         s[p + "rmsnorm_att.weight"] = (C,)
         s[p + "rmsnorm_mlp.weight"] = (C,)
+    if cfg.use_kohonen:
+        m = int((cfg.kohonen_nodes // 2) ** 0.5)
+        n = (cfg.kohonen_nodes // 2) // m
+        s["local_kohonen.nodes"] = (m * n, C)
+        s["global_kohonen.nodes"] = (m * n, C)
+        s["map_balance"] = ()
     s["mlp_head.0.weight"] = (C,)
     s["mlp_head.0.bias"] = (C,)
     s["mlp_head.1.weight"] = (cfg.num_classes, C)
@@ -114,7 +120,11 @@ def formula_state_dict(cfg, perturb_scalars: bool = True, salt: int = 0) -> Dict
     out: Dict[str, torch.Tensor] = {}
     for name, shape in param_shapes(cfg).items():
         leaf = name.split(".")[-1]
-        if name.endswith("pos_embed"):
+        if name == "map_balance":
+            t = torch.tensor(float(cfg.map_balance_weight))
+        elif name.endswith("kohonen.nodes"):
+            t = formula_tensor(name, shape, 1.0, salt=salt)      # reference: randn (kohonen.py:60)
+        elif name.endswith("pos_embed"):
             t = formula_tensor(name, shape, 0.02 if perturb_scalars else 0.0, salt=salt)
         elif name == "sz":
             t = formula_tensor(name, shape, jit * cfg.sz_init_scaling, cfg.sz_init_value, salt)

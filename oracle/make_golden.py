@@ -51,7 +51,21 @@ CASES = [  # (config name, batch)
     ("micro", 8),
     ("mini", 4),
     ("tiny", 32),
+    ("micro_k", 8),   # Kohonen head (BASELINE config C5 semantics at parity size)
+    ("mini_k", 4),
 ]
+AUX_KEYS = ("kohonen_consistency", "kohonen_smoothness", "local_quantization", "global_quantization")
+
+
+def ref_total_loss(cfg, logits, aux, y):
+    """train.py:906-926 with settings.yaml consistency_weight = smoothness_weight = 0.1."""
+    loss = F.cross_entropy(logits, y)
+    if cfg.use_kohonen:
+        loss = (loss + 0.1 * aux["kohonen_consistency"] + 0.1 * aux["kohonen_smoothness"]
+                + cfg.local_quantization_weight * aux["local_quantization"]
+                + cfg.global_quantization_weight * aux["global_quantization"]
+                + cfg.reconstruction_weight * aux["reconstruction"])
+    return loss
 
 
 @torch.no_grad()
@@ -83,16 +97,21 @@ def one_case(name: str, batch: int, renormed: bool) -> dict:
     cfg = named_config(name)
     ref = RefViT(RefConfig(**asdict(cfg)))
     sd = formula_state_dict(cfg, perturb_scalars=True)
-    missing, unexpected = ref.load_state_dict(sd, strict=True), None
+    res = ref.load_state_dict(sd, strict=False)   # only the Kohonen index buffers may be absent from the formula dict
+    assert not res.unexpected_keys and all(k.endswith((".locations", ".offsets")) for k in res.missing_keys), res
     if renormed:
         ref_normalize_matrices(ref)
     ref.train()
     X, y = synthetic_batch(cfg, batch)
     logits, aux = ref(X)
-    loss = F.cross_entropy(logits, y)
+    loss = ref_total_loss(cfg, logits, aux, y)
     loss.backward()
     rec = {"logits": logits.detach().numpy(), "loss": np.float64(loss.item()),
            "recon": np.float64(aux["reconstruction"].item())}
+    if cfg.use_kohonen:
+        rec["aux"] = np.array([aux[k].item() for k in AUX_KEYS])
+        rec["lnodes_head"] = ref.local_kohonen.nodes.detach().reshape(-1)[:8].numpy().copy()   # after the SOM update
+        rec["gnodes_head"] = ref.global_kohonen.nodes.detach().reshape(-1)[:8].numpy().copy()
     names, gn, heads_ = [], [], []
     for n, p in ref.named_parameters():
         if p.grad is None:
@@ -114,7 +133,7 @@ def one_case(name: str, batch: int, renormed: bool) -> dict:
     with torch.no_grad():
         logits1, aux1 = ref(X)
         rec["logits1"] = logits1.numpy()
-        rec["loss1"] = np.float64(F.cross_entropy(logits1, y).item())
+        rec["loss1"] = np.float64(ref_total_loss(cfg, logits1, aux1, y).item())
         rec["recon1"] = np.float64(aux1["reconstruction"].item())
         w = ref.transformer.h[0].query.weight
         rec["q0_head1"] = w.reshape(-1)[:8].numpy().copy()

@@ -17,7 +17,8 @@ What each function restates (citations into /root/reference/):
   lerp           nvit/model.py:134-142    normalised LERP residual
   cross_block    nvit/model.py:219-275
   block          nvit/model.py:92-169 + norm_skip :84-87 (called at :452)
-  forward        nvit/model.py:403-470
+  forward        nvit/model.py:403-470 (both branches: plain cross-attention and the Kohonen head :419-444)
+  bmu/som_update_/map_smoothness/consistency/huber   nvit/kohonen.py:80-165, model.py:482-561
   renorm_        nvit/train.py:461-480    post-step weight re-normalisation
   param_groups   nvit/model.py:369-385    AdamW groups
   train_step     nvit/train.py:898-946,989-990
@@ -163,11 +164,115 @@ def embed(p: Params, cfg, img: Tensor, lowp: LowP) -> Tuple[Tensor, Tensor, Tens
     return loc + p["local_pos_embed"], glo + p["global_pos_embed"], A_l
 
 
-def forward(p: Params, cfg, img: Tensor, lowp: LowP = None, taps: Optional[dict] = None):
-    """-> (logits [B,ncls], {"reconstruction": scalar}); non-Kohonen branch (model.py:445-447)."""
-    assert cfg.use_nvit and not cfg.use_kohonen
+# ---- Kohonen head (BASELINE config C5): /root/reference/nvit/kohonen.py:30-165, model.py:419-444,482-561 ----
+def som_dims(num_nodes: int) -> Tuple[int, int]:
+    m = int(num_nodes ** 0.5)          # kohonen.py:52-54
+    return m, num_nodes // m
+
+
+def bmu(x: Tensor, nodes: Tensor) -> Tensor:
+    """index of the nearest node (L2) for every token: kohonen.py:111-114 (cdist + argmin)."""
+    return torch.argmin(torch.cdist(x, nodes, p=2), dim=-1)
+
+
+def som_neighborhood_d2(bmu_loc: Tensor, m: int, n: int) -> Tensor:
+    """squared periodic grid distance of every node to bmu_loc (kohonen.py:80-98): min over the 9 wrapped copies."""
+    ii, jj = torch.meshgrid(torch.arange(m), torch.arange(n), indexing="ij")
+    loc = torch.stack([ii.reshape(-1), jj.reshape(-1)], dim=1).float()
+    offs = torch.tensor([[0, 0], [-m, -n], [m, n], [-m, 0], [m, 0], [0, -n], [0, n], [-m, n], [m, -n]]).float()
+    d = loc[None, :, :] + offs[:, None, :] - bmu_loc.float()[None, None, :]
+    return (d * d).sum(-1).min(dim=0).values
+
+
+@torch.no_grad()
+def som_update_(nodes: Tensor, x: Tensor, idx: Tensor, lr: float, alpha: float) -> None:
+    """kohonen.py:121-165 literally, including its pairing quirk (SURVEY.md §9.1-Q13): only B iterations;
+    iteration i takes the BMU of FLAT token i and the whole image i pooled T*C -> C by means of T consecutive
+    elements of the flattened [T, C] buffer; updates are sequential."""
+    N, C = nodes.shape
+    m, n = som_dims(N)
+    sigma = (m * n) ** 0.5 / 2.0
+    flat_idx = idx.reshape(-1)
+    B = x.shape[0]
+    for i in range(B):
+        w = int(flat_idx[i])
+        d2 = som_neighborhood_d2(torch.tensor([w // n, w % n]), m, n)
+        strength = lr * alpha * torch.exp(-d2 / (2 * sigma * sigma))
+        v = x[i].reshape(-1)
+        sz = v.numel()
+        if sz > C:
+            v = v.view(-1, sz // C).mean(dim=1)
+        elif sz < C:
+            v = v.repeat(C // sz)
+        nodes.add_(strength[:, None] * (v[None, :] - nodes))
+
+
+def neighbor_indices(idx: Tensor, nodes_per_map: int) -> Tensor:
+    """8-neighbourhood on the periodic map_size x map_size grid (model.py:503-536)."""
+    ms = int(math.sqrt(nodes_per_map))
+    if ms * ms != nodes_per_map:
+        raise ValueError("nodes per map must be a perfect square (SURVEY.md §9.1-Q2)")
+    offs = torch.tensor([[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 1], [1, -1], [1, 0], [1, 1]])
+    row = (idx // ms)[..., None] + offs[:, 0]
+    col = (idx % ms)[..., None] + offs[:, 1]
+    return (row % ms) * ms + (col % ms)
+
+
+def map_smoothness(nodes: Tensor, idx: Tensor) -> Tensor:
+    nb = neighbor_indices(idx, nodes.shape[0])
+    cur = nodes[idx]
+    d = cur[..., None, :] - nodes[nb]
+    return torch.sqrt((d * d).sum(-1)).mean()
+
+
+def consistency(a: Tensor, b: Tensor) -> Tensor:
+    return 1.0 - (nrm(a) * nrm(b)).sum(-1).mean()
+
+
+def huber(a: Tensor, b: Tensor) -> Tensor:
+    d = a - b
+    ad = d.abs()
+    return torch.where(ad < 1.0, 0.5 * d * d, ad - 0.5).mean()
+
+
+def kohonen_lr(cfg, step: int) -> float:
+    if not cfg.kohonen_scheduler_enabled:
+        return cfg.kohonen_alpha
+    w, dcy = cfg.kohonen_scheduler_warmup_steps, cfg.kohonen_scheduler_decay_steps
+    lo, hi = cfg.kohonen_scheduler_min_lr, cfg.kohonen_alpha
+    if step < w:
+        return lo + (hi - lo) * (step / w)
+    if step > dcy:
+        return lo
+    return lo + 0.5 * (1.0 + math.cos(math.pi * (step - w) / (dcy - w))) * (hi - lo)
+
+
+def forward(p: Params, cfg, img: Tensor, lowp: LowP = None, taps: Optional[dict] = None, training: bool = True,
+            step: int = 1):
+    """-> (logits [B,ncls], aux dict).  `step` is the value of ViT.step AFTER its increment (model.py:404-405)."""
+    assert cfg.use_nvit
     loc, glo, A_l = embed(p, cfg, img, lowp)
-    x = cross_block(p, cfg, loc, glo, lowp)
+    aux = {}
+    if cfg.use_kohonen:
+        alpha = cfg.kohonen_alpha if not cfg.kohonen_scheduler_enabled else cfg.kohonen_scheduler_min_lr
+        lr = kohonen_lr(cfg, step)
+        Ln, Gn = p["local_kohonen.nodes"], p["global_kohonen.nodes"]
+        lidx, gidx = bmu(loc.detach(), Ln.detach()), bmu(glo.detach(), Gn.detach())
+        lrepr, grepr = Ln[lidx], Gn[gidx]
+        if training:
+            som_update_(Ln, loc.detach(), lidx, lr, alpha)
+            som_update_(Gn, glo.detach(), gidx, lr, alpha)
+        local_new = cross_block(p, cfg, lrepr, loc, lowp)
+        global_new = cross_block(p, cfg, grepr, glo, lowp)
+        aux["kohonen_consistency"] = consistency(lrepr, grepr)
+        aux["kohonen_smoothness"] = map_smoothness(Ln, lidx) + map_smoothness(Gn, gidx)
+        aux["local_quantization"] = huber(lrepr, loc)
+        aux["global_quantization"] = huber(grepr, glo)
+        x = cross_block(p, cfg, local_new, global_new, lowp)
+        if taps is not None:
+            taps["lidx"], taps["gidx"] = lidx, gidx
+    else:
+        x = cross_block(p, cfg, loc, glo, lowp)
     if taps is not None:
         taps["loc"], taps["glo"], taps["x0"] = loc, glo, x
     for i in range(cfg.n_layer):
@@ -179,8 +284,19 @@ def forward(p: Params, cfg, img: Tensor, lowp: LowP = None, taps: Optional[dict]
     logits = linear(ln, p["mlp_head.1.weight"], p["mlp_head.1.bias"], lowp)
     logits = logits * (p["sz"] * (cfg.sz_init_value / cfg.sz_init_scaling))
     rec = torch.tanh(linear(x, p["reconstruction_head.0.weight"], p["reconstruction_head.0.bias"], lowp))
-    recon = ((rec - A_l) ** 2).mean()
-    return logits, {"reconstruction": recon}
+    aux["reconstruction"] = ((rec - A_l) ** 2).mean()
+    return logits, aux
+
+
+def total_loss(cfg, logits: Tensor, aux, y: Tensor, consistency_weight: float = 0.1, smoothness_weight: float = 0.1):
+    """train.py:906-926: CE, plus the weighted aux losses only when the Kohonen head is on."""
+    loss = cross_entropy(logits, y)
+    if cfg.use_kohonen:
+        loss = (loss + consistency_weight * aux["kohonen_consistency"] + smoothness_weight * aux["kohonen_smoothness"]
+                + cfg.local_quantization_weight * aux["local_quantization"]
+                + cfg.global_quantization_weight * aux["global_quantization"]
+                + cfg.reconstruction_weight * aux["reconstruction"])
+    return loss
 
 
 def cross_entropy(logits: Tensor, y: Tensor) -> Tensor:
@@ -222,12 +338,14 @@ def make_optimizer(p: Params, lr: float = 1e-3, weight_decay: float = 0.1, betas
     return torch.optim.AdamW(param_groups(p, weight_decay), lr=lr, betas=betas)
 
 
-def loss_and_grads(p: Params, cfg, X: Tensor, y: Tensor, lowp: LowP = None):
+def loss_and_grads(p: Params, cfg, X: Tensor, y: Tensor, lowp: LowP = None, step: int = 1, want_aux: bool = False):
     for t in p.values():
         t.grad = None
-    logits, aux = forward(p, cfg, X, lowp)
-    loss = cross_entropy(logits, y)
+    logits, aux = forward(p, cfg, X, lowp, training=True, step=step)
+    loss = total_loss(cfg, logits, aux, y)
     loss.backward()
+    if want_aux:
+        return logits.detach(), loss.detach(), {k: v.detach() for k, v in aux.items()}
     return logits.detach(), loss.detach(), aux["reconstruction"].detach()
 
 
@@ -236,9 +354,9 @@ def total_grad_norm(p: Params) -> Tensor:
     return torch.sqrt(sum((g * g).sum() for g in gs))
 
 
-def train_step(p: Params, cfg, opt, X: Tensor, y: Tensor, grad_clip: float = 1.0, lowp: LowP = None):
+def train_step(p: Params, cfg, opt, X: Tensor, y: Tensor, grad_clip: float = 1.0, lowp: LowP = None, step: int = 1):
     """forward -> CE -> backward -> clip -> AdamW -> zero_grad -> renorm (train.py:898-946,989-990)."""
-    logits, loss, recon = loss_and_grads(p, cfg, X, y, lowp)
+    logits, loss, recon = loss_and_grads(p, cfg, X, y, lowp, step=step)
     gnorm = torch.nn.utils.clip_grad_norm_([t for t in p.values() if t.grad is not None], grad_clip)
     opt.step()
     opt.zero_grad(set_to_none=True)
