@@ -34,7 +34,7 @@ PEAK_HBM_GBS = 8000.0
 def cpu_baseline(cfg_name: str, sample_batch: int, threads: int):
     """Oracle (port of the reference's CPU fp32 semantics) timed on the host cores."""
     from nvit_amd.config import named_config
-    from nvit_amd.weights import formula_state_dict, synthetic_batch
+    from nvit_amd.weights import formula_state_dict, load_formula_weights, synthetic_batch
     from oracle import nvit_oracle as O
     torch.set_num_threads(threads)
     cfg = named_config(cfg_name)
@@ -83,7 +83,7 @@ def main() -> None:
     from nvit_amd.config import named_config, train_flops_per_image
     from nvit_amd.model import ViT
     from nvit_amd.train import normalize_matrices, train_step
-    from nvit_amd.weights import formula_state_dict, synthetic_batch
+    from nvit_amd.weights import formula_state_dict, load_formula_weights, synthetic_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -102,7 +102,7 @@ def main() -> None:
 
     cfg = named_config(args.config)
     model = ViT(cfg)
-    model.load_state_dict(formula_state_dict(cfg, perturb_scalars=False))
+    load_formula_weights(model, cfg, perturb_scalars=False)
     model = model.to(dev).set_precision(args.precision).train()
     normalize_matrices(model)           # steady (unit-norm) state, BASELINE.md §2
     opt = model.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")

@@ -199,6 +199,39 @@ int nvit_pool_ln_bwd(const float* dln, const float* pooled, const float* w, cons
 int nvit_recon_loss(const float* raw, const float* img, float* part, int nblk, float* loss, int B, int ch, int S,
                     int P, void* stream);
 
+/* ---- Kohonen (SOM) head, BASELINE config C5 (kohonen.py:100-165, model.py:419-444,482-561) ---------
+ * nvit_som_bmu: idx[m] = argmin_n ||x_m - node_n||_2 given scores[M,N] = x . node^T (nvit_gemm_nt, fp32) and the
+ *   nodes [N,C] (kohonen.py:111-114 cdist+argmin); nn_ws [N] workspace; first minimum wins.
+ * nvit_gather_rows / nvit_scatter_rows: repr = nodes[idx] (kohonen.py:117) and its backward (fixed order).
+ * nvit_som_update: KohonenMap.update_nodes (kohonen.py:121-165) for the whole batch, in place on nodes [gm*gn, C]:
+ *   B sequential steps; step i uses the BMU of FLAT token i and sample i mean-pooled T*C -> C,
+ *   strength lr_alpha * exp(-d2 / (2 sigma^2)), d2 = periodic grid distance. v_ws [B,C], s_ws [B,gm*gn].
+ * nvit_cos_consistency_*: 1 - mean_m cos(a_m, b_m) (model.py:482-491); stats [M,3] saved for backward.
+ * nvit_huber_*: F.huber_loss(a, b) with delta 1, mean (model.py:441-442).
+ * nvit_som_smooth_*: mean over tokens and 8 periodic grid neighbours of ||node[idx] - node[nb]|| for ONE map
+ *   (model.py:503-561); cnt [N] int32 and D [N,8] workspaces are kept for the backward.
+ * nvit_recon_bwd: d(raw) of mean((tanh(raw) - patch(img))^2) times g[0] (model.py:459-464), type dt. */
+int nvit_som_bmu(const float* scores, const float* nodes, float* nn_ws, int64_t M, int N, int C, int64_t* idx,
+                 void* stream);
+int nvit_gather_rows(const float* nodes, const int64_t* idx, float* out, int64_t M, int C, void* stream);
+int nvit_scatter_rows(const float* dout, const int64_t* idx, float* dnodes, int64_t M, int N, int C, void* stream);
+/* out[M,N] fp32 one-hot rows of idx: the balanced form of the scatter is nvit_gemm_tn(onehot, dout) (exact). */
+int nvit_onehot(const int64_t* idx, float* out, int64_t M, int N, void* stream);
+int nvit_som_update(float* nodes, const float* x, const int64_t* idx, float lr_alpha, float sigma, int gm, int gn,
+                    float* v_ws, float* s_ws, int B, int T, int C, void* stream);
+int nvit_cos_consistency_fwd(const float* a, const float* b, float* stats, float* part, int nblk, float* loss,
+                             int64_t M, int C, void* stream);
+int nvit_cos_consistency_bwd(const float* a, const float* b, const float* stats, const float* g, float* da, float* db,
+                             int64_t M, int C, void* stream);
+int nvit_huber_fwd(const float* a, const float* b, float* part, int nblk, float* loss, int64_t n, void* stream);
+int nvit_huber_bwd(const float* a, const float* b, const float* g, float* da, float* db, int64_t n, void* stream);
+int nvit_som_smooth_fwd(const float* nodes, const int64_t* idx, int* cnt, float* D, float* loss, int64_t M, int Nn,
+                        int C, int map_size, void* stream);
+int nvit_som_smooth_bwd(const float* nodes, const float* D, const int* cnt, const float* g, float* dnodes,
+                        int accumulate, int64_t M, int Nn, int C, int map_size, void* stream);
+int nvit_recon_bwd(int dt, const float* raw, const float* img, const float* g, void* draw, int B, int ch, int S, int P,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -50,6 +50,18 @@ SIGNATURES = {
     "nvit_im2col": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_pool_ln_fwd": [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "nvit_pool_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "nvit_som_bmu": [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp],
+    "nvit_gather_rows": [_vp, _vp, _vp, _i64, _i, _vp],
+    "nvit_scatter_rows": [_vp, _vp, _vp, _i64, _i, _i, _vp],
+    "nvit_onehot": [_vp, _vp, _i64, _i, _vp],
+    "nvit_som_update": [_vp, _vp, _vp, _f, _f, _i, _i, _vp, _vp, _i, _i, _i, _vp],
+    "nvit_cos_consistency_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp],
+    "nvit_cos_consistency_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],
+    "nvit_huber_fwd": [_vp, _vp, _vp, _i, _vp, _i64, _vp],
+    "nvit_huber_bwd": [_vp, _vp, _vp, _vp, _vp, _i64, _vp],
+    "nvit_som_smooth_fwd": [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _i, _vp],
+    "nvit_som_smooth_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp],
+    "nvit_recon_bwd": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "nvit_recon_loss": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp],
 }
 _RESTYPES = {"nvit_last_error": C.c_char_p, "nvit_prof_name": C.c_char_p, "nvit_prof_enable": None}

@@ -29,6 +29,7 @@ from torch import nn
 from . import ops
 from ._lib import BF16, F32
 from .config import ViTConfig
+from .kohonen import CosConsistencyFn, HuberFn, KohonenMap, MapSmoothnessFn
 
 Tensor = torch.Tensor
 
@@ -488,6 +489,35 @@ class _HeadFn(torch.autograd.Function):
         return dx, None, d_lnw, d_lnb, g_pad[:ncls], d_bh, d_sz
 
 
+class _ReconFn(torch.autograd.Function):
+    """reconstruction head + loss: mean((tanh(x W_r^T + b_r) - local patches)^2) (reference model.py:459-464)."""
+
+    @staticmethod
+    def forward(ctx, x, x_lo, rt, img, wr, br):
+        cfg = rt.model.config
+        C, P = cfg.n_embd, cfg.local_patch_size
+        Kl = cfg.channels * P * P
+        M = x.shape[0]
+        raw = ops.gemm_nt(x_lo, rt.sh["rec.W"], M, Kl, C, bias=br)
+        loss = ops.recon_loss(raw, img, P)
+        ctx.rt = rt
+        ctx.dims = (M, C, Kl, P)
+        ctx.save_for_backward(raw, img, x_lo)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        raw, img, x_lo = ctx.saved_tensors
+        rt = ctx.rt
+        M, C, Kl, P = ctx.dims
+        draw = ops.recon_bwd(rt.dt, raw, img, g.contiguous().reshape(1), P)
+        dx = ops.gemm_nt(draw, rt.sh["rec.Wt"], M, C, Kl)
+        g_w = ops.gemm_tn(draw, x_lo, torch.empty((Kl, C), device=raw.device, dtype=torch.float32), M, Kl, C)
+        g_b = torch.empty((Kl,), device=raw.device, dtype=torch.float32)
+        ops.colsum_big(draw, M, Kl, g_b, False)
+        return dx, None, None, None, g_w, g_b
+
+
 # --------------------------------------------------------------------------------------------
 # Modules (parameter containers with the reference's names)
 # --------------------------------------------------------------------------------------------
@@ -591,8 +621,6 @@ class ViT(nn.Module):
         super().__init__()
         if not config.use_nvit:
             raise NotImplementedError("only use_nvit=True is supported (the reference's non-nViT path crashes upstream)")
-        if config.use_kohonen:
-            raise NotImplementedError("the Kohonen head (BASELINE config C5) is not built yet")
         if config.n_embd % config.n_head != 0 or config.n_embd % 64 != 0:
             raise ValueError("n_embd must be a multiple of 64 and divisible by n_head")
         if (config.n_embd // config.n_head) not in (32, 64):
@@ -610,6 +638,11 @@ class ViT(nn.Module):
         self.n_tokens = (config.image_size // Pl) ** 2
         self.local_pos_embed = nn.Parameter(torch.zeros(1, self.n_tokens, C))
         self.global_pos_embed = nn.Parameter(torch.zeros(1, self.n_tokens, C))
+        if config.use_kohonen:   # reference model.py:311-323
+            k_alpha = config.kohonen_alpha if not config.kohonen_scheduler_enabled else config.kohonen_scheduler_min_lr
+            self.local_kohonen = KohonenMap(C, config.kohonen_nodes // 2, k_alpha)
+            self.global_kohonen = KohonenMap(C, config.kohonen_nodes // 2, k_alpha)
+            self.map_balance = nn.Parameter(torch.tensor(config.map_balance_weight))
         self.cross_attention = CrossAttentionBlock(config)
         self.reconstruction_head = nn.Sequential(nn.Linear(C, Pl * Pl * config.channels), nn.Tanh())
         self.transformer = nn.ModuleDict({
@@ -623,6 +656,7 @@ class ViT(nn.Module):
         self.precision = os.environ.get("NVIT_PRECISION", "bf16")
         self.attn_impl = os.environ.get("NVIT_ATTN_IMPL", "auto")
         object.__setattr__(self, "_rt", _Runtime(self))
+        object.__setattr__(self, "_node_sync", None)   # set by DataParallel: averages SOM nodes across ranks
         object.__setattr__(self.cross_attention, "_owner", self)
         for i, blk in enumerate(self.transformer.h):
             object.__setattr__(blk, "_owner", (self, i))
@@ -702,6 +736,41 @@ class ViT(nn.Module):
             return lo
         return lo + 0.5 * (1.0 + math.cos(math.pi * (step - w) / (dcy - w))) * (hi - lo)
 
+    # ---- Kohonen helpers (reference model.py:477-561), same names and semantics
+    def combine_representations(self, local_repr: Tensor, global_repr: Tensor) -> Tensor:
+        raise NotImplementedError("combine_representations is only used by the reference's debug visualisation")
+
+    def compute_consistency_loss(self, local_repr: Tensor, global_repr: Tensor) -> Tensor:
+        Cc = local_repr.shape[-1]
+        return CosConsistencyFn.apply(local_repr.reshape(-1, Cc), global_repr.reshape(-1, Cc))
+
+    def get_neighbor_indices(self, indices: Tensor) -> Tensor:
+        """8-neighbourhood indices on the periodic map (index arithmetic only; the loss kernel recomputes it)."""
+        nodes_per_map = self.config.kohonen_nodes // 2
+        ms = int(math.sqrt(nodes_per_map))
+        if ms * ms != nodes_per_map:
+            raise ValueError(f"Number of nodes per map ({nodes_per_map}) must be a perfect square. "
+                             f"Got {self.config.kohonen_nodes} total nodes.")
+        offs = torch.tensor([[-1, -1], [-1, 0], [-1, 1], [0, -1], [0, 1], [1, -1], [1, 0], [1, 1]],
+                            device=indices.device)
+        row = (indices // ms).unsqueeze(-1) + offs[:, 0]
+        col = (indices % ms).unsqueeze(-1) + offs[:, 1]
+        return (row % ms) * ms + (col % ms)
+
+    def compute_map_smoothness(self, indices: Tensor, neighbor_indices: Optional[Tensor] = None,
+                               is_local: bool = True) -> Tensor:
+        km = self.local_kohonen if is_local else self.global_kohonen
+        nodes_per_map = self.config.kohonen_nodes // 2
+        ms = int(math.sqrt(nodes_per_map))
+        if ms * ms != nodes_per_map or km.grid_size != nodes_per_map:
+            raise ValueError(f"Number of nodes per map ({nodes_per_map}) must be a perfect square. "
+                             f"Got {self.config.kohonen_nodes} total nodes.")
+        return MapSmoothnessFn.apply(km.nodes, indices.reshape(-1).contiguous(), ms)
+
+    def compute_smoothness_loss(self, local_indices: Tensor, global_indices: Tensor) -> Tensor:
+        return (self.compute_map_smoothness(local_indices, None, True)
+                + self.compute_map_smoothness(global_indices, None, False))
+
     def forward(self, img: Tensor) -> Tuple[Tensor, Dict[str, Tensor]]:
         if self.training:
             self.step += 1
@@ -714,14 +783,32 @@ class ViT(nn.Module):
         loc, glo = _EmbedFn.apply(img, rt, self.local_patch_embed.weight, self.local_patch_embed.bias,
                                   self.local_pos_embed, self.global_patch_embed[1].weight,
                                   self.global_patch_embed[1].bias, self.global_pos_embed)
-        x, x_lo = self.cross_attention._run(loc, glo)
+        aux: Dict[str, Tensor] = {}
+        if cfg.use_kohonen:
+            # reference model.py:419-444
+            lr = self.get_kohonen_lr(self.step)
+            loc3, glo3 = loc.reshape(B, T, C), glo.reshape(B, T, C)
+            local_repr, local_idx = self.local_kohonen(loc3)
+            global_repr, global_idx = self.global_kohonen(glo3)
+            if self.training:
+                self.local_kohonen.update_nodes(loc3, local_idx, lr)
+                self.global_kohonen.update_nodes(glo3, global_idx, lr)
+                if self._node_sync is not None:   # data parallel: keep the SOM replicas identical
+                    self._node_sync(self.local_kohonen.nodes.data, self.global_kohonen.nodes.data)
+            lrep2, grep2 = local_repr.reshape(B * T, C), global_repr.reshape(B * T, C)
+            local_new, _ = self.cross_attention._run(lrep2, loc)
+            global_new, _ = self.cross_attention._run(grep2, glo)
+            aux["kohonen_consistency"] = self.compute_consistency_loss(local_repr, global_repr)
+            aux["kohonen_smoothness"] = self.compute_smoothness_loss(local_idx, global_idx)
+            aux["local_quantization"] = HuberFn.apply(lrep2, loc)
+            aux["global_quantization"] = HuberFn.apply(grep2, glo)
+            x, x_lo = self.cross_attention._run(local_new, global_new)
+        else:
+            x, x_lo = self.cross_attention._run(loc, glo)
         for blk in self.transformer.h:
             x, x_lo = blk._run(x, x_lo, True)
         logits = _HeadFn.apply(x, rt, self.mlp_head[0].weight, self.mlp_head[0].bias, self.mlp_head[1].weight,
                                self.mlp_head[1].bias, self.sz)
-        aux: Dict[str, Tensor] = {}
-        with torch.no_grad():
-            Kl = cfg.channels * cfg.local_patch_size ** 2
-            raw = ops.gemm_nt(x_lo, rt.sh["rec.W"], B * T, Kl, C, bias=self.reconstruction_head[0].bias)
-            aux["reconstruction"] = ops.recon_loss(raw, img, cfg.local_patch_size)
+        aux["reconstruction"] = _ReconFn.apply(x, x_lo, rt, img, self.reconstruction_head[0].weight,
+                                               self.reconstruction_head[0].bias)
         return logits, aux

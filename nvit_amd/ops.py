@@ -359,6 +359,106 @@ def recon_loss(raw: Tensor, img: Tensor, P: int) -> Tensor:
     return loss.reshape(())
 
 
+# ----------------------------------------------------------------------------- Kohonen head (config C5)
+def som_bmu(x: Tensor, nodes: Tensor) -> Tensor:
+    """x [M,C] fp32, nodes [N,C] fp32 -> idx [M] int64 (exact-f32 MFMA score GEMM + argmin kernel)."""
+    M, Cc = x.shape
+    N = nodes.shape[0]
+    scores = gemm_nt(x, nodes, M, N, Cc)                      # fp32 operands -> v_mfma_f32_16x16x4_f32
+    nn_ws = torch.empty((N,), device=x.device, dtype=torch.float32)
+    idx = torch.empty((M,), device=x.device, dtype=torch.int64)
+    check(_lib.load().nvit_som_bmu(_p(scores), _p(nodes), _p(nn_ws), M, N, Cc, _p(idx), _s()), "nvit_som_bmu")
+    return idx
+
+
+def gather_rows(nodes: Tensor, idx: Tensor) -> Tensor:
+    M, Cc = idx.numel(), nodes.shape[1]
+    out = torch.empty((M, Cc), device=nodes.device, dtype=torch.float32)
+    check(_lib.load().nvit_gather_rows(_p(nodes), _p(idx), _p(out), M, Cc, _s()), "nvit_gather_rows")
+    return out
+
+
+def scatter_rows(dout: Tensor, idx: Tensor, N: int) -> Tensor:
+    """dnodes[n] = sum of dout rows with idx == n.  All tokens may pick the same node (they do at init: the BMU of a
+    small-norm patch is the smallest-norm node), so instead of a per-node loop this is onehot(idx)^T . dout on the
+    exact-f32 weight-gradient GEMM: load balanced and deterministic whatever the histogram."""
+    M, Cc = dout.shape
+    dn = torch.empty((N, Cc), device=dout.device, dtype=torch.float32)
+    if N % 4 != 0 or Cc % 4 != 0:
+        check(_lib.load().nvit_scatter_rows(_p(dout), _p(idx), _p(dn), M, N, Cc, _s()), "nvit_scatter_rows")
+        return dn
+    oh = torch.empty((M, N), device=dout.device, dtype=torch.float32)
+    check(_lib.load().nvit_onehot(_p(idx), _p(oh), M, N, _s()), "nvit_onehot")
+    return gemm_tn(oh, dout.float().contiguous(), dn, M, N, Cc)
+
+
+def som_update(nodes: Tensor, x: Tensor, idx: Tensor, lr_alpha: float, sigma: float, gm: int, gn: int, B: int,
+               T: int) -> None:
+    Cc = nodes.shape[1]
+    v_ws = torch.empty((B, Cc), device=nodes.device, dtype=torch.float32)
+    s_ws = torch.empty((B, gm * gn), device=nodes.device, dtype=torch.float32)
+    check(_lib.load().nvit_som_update(_p(nodes), _p(x), _p(idx), lr_alpha, sigma, gm, gn, _p(v_ws), _p(s_ws), B, T, Cc,
+                                      _s()), "nvit_som_update")
+
+
+def cos_consistency_fwd(a: Tensor, b: Tensor):
+    M, Cc = a.shape
+    nblk = min(1024, math.ceil(M / 4))
+    stats = torch.empty((M, 3), device=a.device, dtype=torch.float32)
+    part = torch.empty((nblk,), device=a.device, dtype=torch.float32)
+    loss = torch.empty((1,), device=a.device, dtype=torch.float32)
+    check(_lib.load().nvit_cos_consistency_fwd(_p(a), _p(b), _p(stats), _p(part), nblk, _p(loss), M, Cc, _s()),
+          "nvit_cos_consistency_fwd")
+    return loss.reshape(()), stats
+
+
+def cos_consistency_bwd(a: Tensor, b: Tensor, stats: Tensor, g: Tensor):
+    M, Cc = a.shape
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    check(_lib.load().nvit_cos_consistency_bwd(_p(a), _p(b), _p(stats), _p(g), _p(da), _p(db), M, Cc, _s()),
+          "nvit_cos_consistency_bwd")
+    return da, db
+
+
+def huber_fwd(a: Tensor, b: Tensor) -> Tensor:
+    nblk = 1024
+    part = torch.empty((nblk,), device=a.device, dtype=torch.float32)
+    loss = torch.empty((1,), device=a.device, dtype=torch.float32)
+    check(_lib.load().nvit_huber_fwd(_p(a), _p(b), _p(part), nblk, _p(loss), a.numel(), _s()), "nvit_huber_fwd")
+    return loss.reshape(())
+
+
+def huber_bwd(a: Tensor, b: Tensor, g: Tensor):
+    da, db = torch.empty_like(a), torch.empty_like(b)
+    check(_lib.load().nvit_huber_bwd(_p(a), _p(b), _p(g), _p(da), _p(db), a.numel(), _s()), "nvit_huber_bwd")
+    return da, db
+
+
+def som_smooth_fwd(nodes: Tensor, idx: Tensor, map_size: int):
+    Nn, Cc = nodes.shape
+    cnt = torch.empty((Nn,), device=nodes.device, dtype=torch.int32)
+    D = torch.empty((Nn, 8), device=nodes.device, dtype=torch.float32)
+    loss = torch.empty((1,), device=nodes.device, dtype=torch.float32)
+    check(_lib.load().nvit_som_smooth_fwd(_p(nodes), _p(idx), _p(cnt), _p(D), _p(loss), idx.numel(), Nn, Cc, map_size,
+                                          _s()), "nvit_som_smooth_fwd")
+    return loss.reshape(()), cnt, D
+
+
+def som_smooth_bwd(nodes: Tensor, D: Tensor, cnt: Tensor, g: Tensor, M: int, map_size: int) -> Tensor:
+    Nn, Cc = nodes.shape
+    dn = torch.empty_like(nodes)
+    check(_lib.load().nvit_som_smooth_bwd(_p(nodes), _p(D), _p(cnt), _p(g), _p(dn), 0, M, Nn, Cc, map_size, _s()),
+          "nvit_som_smooth_bwd")
+    return dn
+
+
+def recon_bwd(dt: int, raw: Tensor, img: Tensor, g: Tensor, P: int) -> Tensor:
+    B, ch, S, _ = img.shape
+    draw = torch.empty(raw.shape, device=raw.device, dtype=tdtype(dt))
+    check(_lib.load().nvit_recon_bwd(dt, _p(raw), _p(img), _p(g), _p(draw), B, ch, S, P, _s()), "nvit_recon_bwd")
+    return draw
+
+
 # ----------------------------------------------------------------------------- weights
 def renorm_table(mats, device) -> Tuple[Tensor, int]:
     """mats: list of (tensor fp32 [rows, cols] contiguous, dim). -> device table, total_items"""

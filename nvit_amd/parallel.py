@@ -62,6 +62,14 @@ class DataParallel(nn.Module):
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t.data, src=0, group=process_group)
+        # Kohonen head (config C5): the SOM nodes are mutated inside forward from rank-local data and the reference
+        # never re-synchronises them; policy here: average the freshly updated nodes across ranks.
+        if hasattr(module, "_node_sync"):
+            def _sync_nodes(*tensors):
+                for t in tensors:
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
+                    t.div_(self.world)
+            object.__setattr__(module, "_node_sync", _sync_nodes)
         self._params = [p for p in module.parameters() if p.requires_grad]
         for p in self._params:
             p.register_post_accumulate_grad_hook(self._hook)

@@ -49,11 +49,24 @@ def normalize_matrices(model) -> None:
     ops.renorm_weights(cache[1], cache[2])
 
 
+def total_loss(config, logits: torch.Tensor, aux, y: torch.Tensor, consistency_weight: float = 0.1,
+               smoothness_weight: float = 0.1) -> torch.Tensor:
+    """Loss of the reference loop (train.py:906-926): CE, plus the weighted aux losses iff the Kohonen head is on
+    (consistency/smoothness weights are settings.yaml `training.*`, the others come from the model config)."""
+    loss = F.cross_entropy(logits, y)
+    if config.use_kohonen:
+        loss = (loss + consistency_weight * aux["kohonen_consistency"] + smoothness_weight * aux["kohonen_smoothness"]
+                + config.local_quantization_weight * aux["local_quantization"]
+                + config.global_quantization_weight * aux["global_quantization"]
+                + config.reconstruction_weight * aux["reconstruction"])
+    return loss
+
+
 def train_step(model, optimizer, X: torch.Tensor, y: torch.Tensor, grad_clip: float = 1.0,
                sync_grads=None):
     """One optimizer step in the reference's order; returns (logits, loss, aux, grad_norm)."""
     logits, aux = model(X)
-    loss = F.cross_entropy(logits, y)
+    loss = total_loss(_unwrap(model).config, logits, aux, y)
     loss.backward()
     if sync_grads is not None:
         sync_grads()

@@ -162,3 +162,12 @@ def synthetic_batch(cfg, batch: int, seed: int = 1234, salt: int = 0):
     u = (unit_uniform(f"y{seed}", batch, salt) + 1.0) * 0.5
     y = torch.from_numpy(np.minimum((u * cfg.num_classes).astype(np.int64), cfg.num_classes - 1))
     return X, y
+
+
+def load_formula_weights(model, cfg, **kw) -> None:
+    """model.load_state_dict(formula_state_dict(cfg)); only the Kohonen index buffers (locations / offsets, which
+    the module builds itself) may be absent from the formula dictionary."""
+    res = model.load_state_dict(formula_state_dict(cfg, **kw), strict=False)
+    bad = [k for k in res.missing_keys if not k.endswith((".locations", ".offsets"))]
+    if bad or res.unexpected_keys:
+        raise RuntimeError(f"formula weights do not match the module: missing {bad}, unexpected {res.unexpected_keys}")
