@@ -126,6 +126,12 @@ int nvit_lerp_bwd(int dt, const float* dout, const float* h, const void* y, int 
                   void* dy_lo, float* dskip_x, float* part_dlam, float* part_dskip, int nblk, int M, int C,
                   void* stream);
 
+/* Block.norm_skip on its own (model.py:84-87): out = nrm(src*skip[0] + tgt), fp32 [M,C]; backward writes dsrc, dtgt
+ * and part_dskip [nblk]. (ViT.forward uses the copy fused into nvit_lerp_fwd/bwd.) */
+int nvit_norm_skip_fwd(const float* src, const float* tgt, const float* skip, float* out, int M, int C, void* stream);
+int nvit_norm_skip_bwd(const float* dout, const float* src, const float* tgt, const float* skip, float* dsrc,
+                       float* dtgt, float* part_dskip, int nblk, int M, int C, void* stream);
+
 /* nvit_qknorm_fwd: per-head cosine normalise + learned scale + head split (model.py:104-119,231-247)
  * q/k/v sources: row-major, type dt, row stride ld* elements, C columns each.
  * qh = (sqk*c_q) * nrm_d(q) etc. written [B,H,T,d] type dt; v copied to [B,H,T,d];

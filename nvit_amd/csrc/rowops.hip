@@ -205,6 +205,59 @@ __global__ __launch_bounds__(256) void lerp_bwd_kernel(LerpBwdArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------ standalone norm_skip
+// out = nrm(source*skip + target)  (Block.norm_skip, reference model.py:84-87) for callers that use it on its own;
+// ViT.forward uses the version fused into lerp_fwd/bwd.
+template <int NV>
+__global__ __launch_bounds__(256) void norm_skip_fwd_kernel(const float* src, const float* tgt, const float* skip,
+                                                             float* out, int M, int C) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float sk = skip[0];
+  for (int m = blockIdx.x * ROW_WAVES + wid; m < M; m += gridDim.x * ROW_WAVES) {
+    RowVec<NV> a, b;
+    row_load<NV, float>(a, src + (size_t)m * C, C, lane);
+    row_load<NV, float>(b, tgt + (size_t)m * C, C, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a.v[i] = a.v[i] * sk + b.v[i];
+    const float rs = 1.0f / sqrtf(row_dot<NV>(a, a));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a.v[i] = a.v[i] * rs;
+    row_store<NV, float>(a, out + (size_t)m * C, C, lane);
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void norm_skip_bwd_kernel(const float* dout, const float* src, const float* tgt,
+                                                             const float* skip, float* dsrc, float* dtgt,
+                                                             float* part_dskip, int M, int C) {
+  __shared__ float red[ROW_WAVES];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const float sk = skip[0];
+  float acc = 0.f;
+  for (int m = blockIdx.x * ROW_WAVES + wid; m < M; m += gridDim.x * ROW_WAVES) {
+    RowVec<NV> a, b, g;
+    row_load<NV, float>(a, src + (size_t)m * C, C, lane);
+    row_load<NV, float>(b, tgt + (size_t)m * C, C, lane);
+    row_load<NV, float>(g, dout + (size_t)m * C, C, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) b.v[i] = a.v[i] * sk + b.v[i];
+    const float rs = 1.0f / sqrtf(row_dot<NV>(b, b));
+#pragma unroll
+    for (int i = 0; i < NV; ++i) b.v[i] = b.v[i] * rs;
+    const float og = row_dot<NV>(b, g);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) g.v[i] = (g.v[i] - b.v[i] * og) * rs;  // d(source*skip + target)
+    acc += row_dot<NV>(g, a);
+    row_store<NV, float>(g, dtgt + (size_t)m * C, C, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) g.v[i] = g.v[i] * sk;
+    row_store<NV, float>(g, dsrc + (size_t)m * C, C, lane);
+  }
+  if (lane == 0) red[wid] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part_dskip[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 // ------------------------------------------------------------------------------ q/k normalise
 struct QkArgs {
   const void *q, *k, *v;
@@ -509,6 +562,28 @@ extern "C" int nvit_lerp_bwd(int dt, const float* dout, const float* h, const vo
       hipLaunchKernelGGL((lerp_bwd_kernel<NV, bf16, bf16>), dim3(nblk), dim3(256), 0, s, a);
   });
   NVIT_CHECK_LAUNCH("lerp_bwd");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_norm_skip_fwd(const float* src, const float* tgt, const float* skip, float* out, int M, int C,
+                                  void* stream) {
+  NVIT_REQUIRE(C % 4 == 0 && C <= 2048 && M > 0, "norm_skip_fwd: C=%d must be a multiple of 4 and <= 2048", C);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = row_grid(M);
+  DISPATCH_NV(C, { hipLaunchKernelGGL((norm_skip_fwd_kernel<NV>), dim3(grid), dim3(256), 0, s, src, tgt, skip, out, M, C); });
+  NVIT_CHECK_LAUNCH("norm_skip_fwd");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_norm_skip_bwd(const float* dout, const float* src, const float* tgt, const float* skip, float* dsrc,
+                                  float* dtgt, float* part_dskip, int nblk, int M, int C, void* stream) {
+  NVIT_REQUIRE(C % 4 == 0 && C <= 2048 && M > 0 && nblk > 0 && nblk <= 4096, "norm_skip_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_NV(C, {
+    hipLaunchKernelGGL((norm_skip_bwd_kernel<NV>), dim3(nblk), dim3(256), 0, s, dout, src, tgt, skip, dsrc, dtgt,
+                       part_dskip, M, C);
+  });
+  NVIT_CHECK_LAUNCH("norm_skip_bwd");
   return NVIT_OK;
 }
 

@@ -489,6 +489,21 @@ class _HeadFn(torch.autograd.Function):
         return dx, None, d_lnw, d_lnb, g_pad[:ncls], d_bh, d_sz
 
 
+class _NormSkipFn(torch.autograd.Function):
+    """Block.norm_skip as a standalone call (reference model.py:84-87)."""
+
+    @staticmethod
+    def forward(ctx, source, target, skip):
+        source, target = source.contiguous().float(), target.contiguous().float()
+        ctx.save_for_backward(source, target, skip)
+        return ops.norm_skip_fwd(source, target, skip)
+
+    @staticmethod
+    def backward(ctx, dout):
+        source, target, skip = ctx.saved_tensors
+        return ops.norm_skip_bwd(dout.contiguous(), source, target, skip)
+
+
 class _ReconFn(torch.autograd.Function):
     """reconstruction head + loss: mean((tanh(x W_r^T + b_r) - local patches)^2) (reference model.py:459-464)."""
 
@@ -563,6 +578,16 @@ class Block(nn.Module):
         rt = model._rt
         xn, xn_lo = _BlockFn.apply(x, x_lo, rt, idx, with_skip, model._attn_impl(), *self._args())
         return xn, _lo(rt, xn, xn_lo)
+
+    def norm_skip(self, source: Tensor, target: Tensor) -> Tensor:
+        """nrm(source * skip_param + target) (reference model.py:84-87)."""
+        shp = source.shape
+        Cc = shp[-1]
+        out = _NormSkipFn.apply(source.reshape(-1, Cc), target.reshape(-1, Cc), self.skip_param)
+        return out.reshape(shp)
+
+    def justnorm(self, x: Tensor) -> Tensor:
+        raise NotImplementedError("justnorm is fused into the HIP kernels; it has no standalone entry point here")
 
     def forward(self, h: Tensor) -> Tensor:
         """h [B,T,C] -> [B,T,C] (block output BEFORE norm_skip, like the reference)."""

@@ -196,6 +196,25 @@ def lerp_bwd(dt: int, dout: Tensor, h: Tensor, y: Tensor, alpha: Tensor, c_a: fl
     return dh, dy, dy_lo, dskip_x, part, pskip
 
 
+def norm_skip_fwd(src: Tensor, tgt: Tensor, skip: Tensor) -> Tensor:
+    M, Cc = src.shape
+    out = torch.empty_like(src)
+    check(_lib.load().nvit_norm_skip_fwd(_p(src), _p(tgt), _p(skip), _p(out), M, Cc, _s()), "nvit_norm_skip_fwd")
+    return out
+
+
+def norm_skip_bwd(dout: Tensor, src: Tensor, tgt: Tensor, skip: Tensor):
+    M, Cc = src.shape
+    nblk = min(PART_BLOCKS, math.ceil(M / 4))
+    dsrc, dtgt = torch.empty_like(src), torch.empty_like(src)
+    part = torch.empty((nblk,), device=src.device, dtype=torch.float32)
+    check(_lib.load().nvit_norm_skip_bwd(_p(dout), _p(src), _p(tgt), _p(skip), _p(dsrc), _p(dtgt), _p(part), nblk, M,
+                                         Cc, _s()), "nvit_norm_skip_bwd")
+    dskip = torch.empty_like(skip)
+    colsum_reduce(part, dskip, False)
+    return dsrc, dtgt, dskip
+
+
 def qknorm_fwd(dt: int, q: Tensor, ldq: int, k: Tensor, ldk: int, v: Tensor, ldv: int, sqk: Tensor, c_q: float,
                B: int, T: int, H: int, d: int):
     dev = sqk.device

@@ -236,3 +236,28 @@ def test_kohonen_head_bf16_runs_and_tracks_oracle():
     assert eemu < 1.5e-2 and e32 < 6e-2
     assert abs(loss.item() - loss_ref.item()) < 2e-2 * abs(loss_ref.item())
     assert torch.isfinite(gnorm).item()
+
+
+def test_block_forward_and_norm_skip_standalone_api():
+    """Reference call pattern of model.py:450-452 through the PUBLIC methods: patches_new = block(patches);
+    patches = block.norm_skip(patches_new, patches) — must equal the fused path used by ViT.forward."""
+    cfg = named_config("mini")
+    m = build(cfg, "fp32", True).train()
+    B, T, C = 3, m.n_tokens, cfg.n_embd
+    x = torch.nn.functional.normalize(torch.randn(B, T, C, generator=torch.Generator().manual_seed(5)), dim=-1)
+    p = O.make_params(formula_state_dict(cfg))
+    O.renorm_(p, cfg)
+    xr = x.clone().requires_grad_(True)
+    ref = O.block(p, cfg, 0, xr, None)
+    g = torch.randn(B, T, C, generator=torch.Generator().manual_seed(6))
+    ref.backward(g)
+    blk = m.transformer.h[0]
+    xg = x.cuda().requires_grad_(True)
+    new = blk(xg)
+    out = blk.norm_skip(new, xg)
+    out.backward(g.cuda())
+    assert (out.detach().cpu() - ref.detach()).abs().max().item() < 1e-6
+    assert (xg.grad.cpu() - xr.grad).abs().max().item() < 2e-5 * max(1.0, xr.grad.abs().max().item())
+    gs = blk.skip_param.grad.cpu()
+    assert (gs - p["transformer.h.0.skip_param"].grad).abs().max().item() < 2e-4 * max(
+        1.0, p["transformer.h.0.skip_param"].grad.abs().max().item())
