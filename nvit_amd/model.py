@@ -71,6 +71,33 @@ class _Runtime:
         self.items = 0
         self.btable = None
         self.bitems = 0
+        # weight-gradient GEMMs run on a side HIP stream so that the HBM-bound row kernels of the data-gradient
+        # chain (lerp / SwiGLU backward) overlap them instead of queueing behind them (NVIT_SIDE_STREAM=0 disables)
+        self.use_side = os.environ.get("NVIT_SIDE_STREAM", "0") == "1"  # measured: no gain (the persistent GEMMs fill registers + LDS)
+        self.side = None
+        self._keep: List[Tensor] = []
+
+    def on_side(self, fn, *keep):
+        """Run fn() (kernel launches only; outputs must be pre-allocated by the caller) on the side stream,
+        ordered after everything enqueued so far on the current stream.  `keep`: tensors the side work reads,
+        held until join() so the caching allocator cannot hand their memory to later main-stream kernels."""
+        if not self.use_side:
+            return fn()
+        if self.side is None:
+            self.side = torch.cuda.Stream()
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.side.wait_event(ev)
+        self._keep.extend(keep)
+        with torch.cuda.stream(self.side):
+            return fn()
+
+    def join(self) -> None:
+        if self.use_side and self.side is not None:
+            ev = torch.cuda.Event()
+            ev.record(self.side)
+            torch.cuda.current_stream().wait_event(ev)
+        self._keep.clear()
 
     def _build(self, device, dt: int) -> None:
         m, cfg = self.model, self.model.config
@@ -266,18 +293,16 @@ class _BlockFn(torch.autograd.Function):
             dx, dskip = None, None
         d_mlp_alpha = _param_grad_alpha(part_lam, mlp_alpha, c_a)
         dxm = ops.gemm_nt(dy2_lo, sh[pre + "p.Wt"], M, 4 * C, C, out_dtype=td)
-        g_wp = ops.gemm_tn(dy2_lo, xm, torch.empty((C, 4 * C), device=x.device, dtype=torch.float32), M, C, 4 * C)
+        g_wp = torch.empty((C, 4 * C), device=x.device, dtype=torch.float32)
+        rt.on_side(lambda: ops.gemm_tn(dy2_lo, xm, g_wp, M, C, 4 * C), dy2_lo, xm)
         g_bp = _bias_grad(dy2_lo, M, C) if ctx.has_b else None
-        del dy2_lo
         gscale = math.sqrt(C)
         duv, part_suv = ops.swiglu_bwd(dt, dxm, uv, suv, gscale, M, 4 * C)
-        del dxm
         d_suv = _param_grad_scaled(part_suv, suv, 1.0)
         ops.gemm_nt(duv, sh[pre + "fc.Wt"], M, C, 8 * C, out=dh1, accumulate=True)
-        g_wfc = ops.gemm_tn(duv, h1_lo, torch.empty((8 * C, C), device=x.device, dtype=torch.float32), M, 8 * C, C,
-                            perm=1)
+        g_wfc = torch.empty((8 * C, C), device=x.device, dtype=torch.float32)
+        rt.on_side(lambda: ops.gemm_tn(duv, h1_lo, g_wfc, M, 8 * C, C, perm=1), duv, h1_lo)
         g_bfc = _bias_grad(duv, M, 8 * C, perm=1) if ctx.has_b else None
-        del duv
         # ---- attention half
         if dx is None:
             dx, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dh1, x, y, attn_alpha, c_a, None, None, None, False,
@@ -287,9 +312,9 @@ class _BlockFn(torch.autograd.Function):
                                                         True)
         d_attn_alpha = _param_grad_alpha(part_lam, attn_alpha, c_a)
         do = ops.gemm_nt(dy_lo, sh[pre + "o.Wt"], M, C, C, out_dtype=td)
-        g_wo = ops.gemm_tn(dy_lo, o, torch.empty((C, C), device=x.device, dtype=torch.float32), M, C, C)
+        g_wo = torch.empty((C, C), device=x.device, dtype=torch.float32)
+        rt.on_side(lambda: ops.gemm_tn(dy_lo, o, g_wo, M, C, C), dy_lo, o)
         g_bo = _bias_grad(dy_lo, M, C) if ctx.has_b else None
-        del dy_lo
         dqkv = torch.empty((M, 3 * C), device=x.device, dtype=td)
         if impl == 1 and d == 64 and dt != F32:
             # attention backward with the q/k-normalise backward fused into its epilogues
@@ -303,8 +328,10 @@ class _BlockFn(torch.autograd.Function):
                                       dqkv[:, 2 * C:], 3 * C, B, T, H, d)
             d_sqk = _param_grad_scaled(part_sqk, sqk, c_q)
         ops.gemm_nt(dqkv, sh[pre + "qkv.Wt"], M, C, 3 * C, out=dx, accumulate=True)
-        g_qkv = ops.gemm_tn(dqkv, x_lo, torch.empty((3 * C, C), device=x.device, dtype=torch.float32), M, 3 * C, C)
+        g_qkv = torch.empty((3 * C, C), device=x.device, dtype=torch.float32)
+        rt.on_side(lambda: ops.gemm_tn(dqkv, x_lo, g_qkv, M, 3 * C, C), dqkv, x_lo)
         g_bqkv = _bias_grad(dqkv, M, 3 * C) if ctx.has_b else None
+        rt.join()
         gq, gk, gv = g_qkv[:C], g_qkv[C:2 * C], g_qkv[2 * C:]
         if ctx.has_b:
             gbq, gbk, gbv = g_bqkv[:C], g_bqkv[C:2 * C], g_bqkv[2 * C:]
