@@ -87,12 +87,42 @@ __device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid
   }
 }
 
+// LDS-DMA staging (global_load_lds_dwordx4 from inline asm, see gemm_common.h for why): lane L lands at
+// lds_off + 16*L.  One wave-instruction = 8 rows of a 128-byte-row tile; the XOR swizzle is realised by
+// fetching chunk (L&7) ^ (row&7).
+__device__ __forceinline__ void glds16a(const void* gsrc, unsigned lds_off) {
+  unsigned keep;
+  const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_off);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(m)
+      : "memory");
+}
+// DMA one 64-row tile of `src` (row stride ld elements, rows clamped to nrows-1) to LDS byte offset tile_off;
+// 4 waves x 2 wave-instructions.  TILE_DMA = instructions per wave per tile.
+constexpr int TILE_DMA = 2;
+__device__ __forceinline__ void tile_dma(const bf16* src, size_t ld, int row_base, int nrows, unsigned tile_off,
+                                         int lane, int wid) {
+  const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
+#pragma unroll
+  for (int i = 0; i < TILE_DMA; ++i) {
+    const int grp = i * 4 + wid;
+    int row = row_base + grp * 8 + r8;
+    row = row < nrows ? row : nrows - 1;
+    glds16a(src + (size_t)row * ld + chunk * 8, tile_off + grp * 1024);
+  }
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)p);
+}
+
 // ------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restrict__ qh, const bf16* __restrict__ kh,
+__global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __restrict__ qh, const bf16* __restrict__ kh,
                                                              const bf16* __restrict__ vh, float scale,
                                                              bf16* __restrict__ o, float* __restrict__ lse, int H,
                                                              int Tq, int Tk) {
-  __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];  // [buf][K|V]
+  __shared__ __attribute__((aligned(16))) char lds[3][2][TILE_BYTES];  // ring [slot][K|V]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
@@ -118,18 +148,24 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
   float m_[2] = {-INFINITY, -INFINITY}, l_[2] = {0.f, 0.f};
 
   const int nt = (Tk + TKV - 1) / TKV;
-  Stage2 sk, sv;
-  stage_load(sk, kbase, D, 0, Tk, tid);
-  stage_load(sv, vbase, D, 0, Tk, tid);
-  stage_store(sk, &lds[0][0][0], tid);
-  stage_store(sv, &lds[0][1][0], tid);
+  // K/V ring: LDS-DMA two tiles ahead, counted vmcnt (4 younger DMA instructions may stay in flight)
+  const unsigned ring = lds_addr(&lds[0][0][0]);
+  tile_dma(kbase, D, 0, Tk, ring, lane, wid);
+  tile_dma(vbase, D, 0, Tk, ring + TILE_BYTES, lane, wid);
+  if (nt > 1) {
+    tile_dma(kbase, D, TKV, Tk, ring + 2 * TILE_BYTES, lane, wid);
+    tile_dma(vbase, D, TKV, Tk, ring + 3 * TILE_BYTES, lane, wid);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    {
-      const int tn = (t + 1 < nt) ? t + 1 : t;
-      stage_load(sk, kbase, D, tn * TKV, Tk, tid);
-      stage_load(sv, vbase, D, tn * TKV, Tk, tid);
+    if (t + 2 < nt) {
+      const int sl = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
+      tile_dma(kbase, D, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid);
+      tile_dma(vbase, D, (t + 2) * TKV, Tk, ring + (2 * sl + 1) * TILE_BYTES, lane, wid);
     }
     const char* kt = &lds[cur][0][0];
     const char* vt = &lds[cur][1][0];
@@ -194,10 +230,12 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const bf16* __restri
 #pragma unroll
         for (int f = 0; f < 2; ++f) oacc[df][f] = mfma16(va, pf[s2][f], oacc[df][f]);
       }
-    stage_store(sk, &lds[cur ^ 1][0][0], tid);
-    stage_store(sv, &lds[cur ^ 1][1][0], tid);
+    if (t + 2 < nt)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
+    cur = cur == 2 ? 0 : cur + 1;
   }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
@@ -284,12 +322,12 @@ __device__ __forceinline__ void qk_bwd_epilogue(f32x4 (&g)[4][2], const bf16* xh
 
 // ------------------------------------------------------------------------------------------ dQ
 template <bool FUSE>
-__global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
                                                                 const bf16* __restrict__ kh, const bf16* __restrict__ vh,
                                                                 const float* __restrict__ lse,
                                                                 const float* __restrict__ delta, float scale,
                                                                 bf16* __restrict__ dqh, int H, int Tq, int Tk, QkFuse fu) {
-  __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char lds[3][2][TILE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const int bh = blockIdx.y, b = bh / H, h = bh % H;
@@ -319,18 +357,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __res
     for (int f = 0; f < 2; ++f) dq[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nt = (Tk + TKV - 1) / TKV;
-  Stage2 sk, sv;
-  stage_load(sk, kbase, D, 0, Tk, tid);
-  stage_load(sv, vbase, D, 0, Tk, tid);
-  stage_store(sk, &lds[0][0][0], tid);
-  stage_store(sv, &lds[0][1][0], tid);
+  // K/V ring: LDS-DMA two tiles ahead, counted vmcnt (4 younger DMA instructions may stay in flight)
+  const unsigned ring = lds_addr(&lds[0][0][0]);
+  tile_dma(kbase, D, 0, Tk, ring, lane, wid);
+  tile_dma(vbase, D, 0, Tk, ring + TILE_BYTES, lane, wid);
+  if (nt > 1) {
+    tile_dma(kbase, D, TKV, Tk, ring + 2 * TILE_BYTES, lane, wid);
+    tile_dma(vbase, D, TKV, Tk, ring + 3 * TILE_BYTES, lane, wid);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   __syncthreads();
   int cur = 0;
   for (int t = 0; t < nt; ++t) {
-    {
-      const int tn = (t + 1 < nt) ? t + 1 : t;
-      stage_load(sk, kbase, D, tn * TKV, Tk, tid);
-      stage_load(sv, vbase, D, tn * TKV, Tk, tid);
+    if (t + 2 < nt) {
+      const int sl = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
+      tile_dma(kbase, D, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid);
+      tile_dma(vbase, D, (t + 2) * TKV, Tk, ring + (2 * sl + 1) * TILE_BYTES, lane, wid);
     }
     const char* kt = &lds[cur][0][0];
     const char* vt = &lds[cur][1][0];
@@ -372,10 +416,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __res
 #pragma unroll
         for (int f = 0; f < 2; ++f) dq[df][f] = mfma16(ka, dsf[s2][f], dq[df][f]);
       }
-    stage_store(sk, &lds[cur ^ 1][0][0], tid);
-    stage_store(sv, &lds[cur ^ 1][1][0], tid);
+    if (t + 2 < nt)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
+    cur = cur == 2 ? 0 : cur + 1;
   }
   if constexpr (FUSE) {
     qk_bwd_epilogue(dq, qh + (size_t)bh * Tq * D, fu, q0, Tq, H, b, h, lane, wid, reinterpret_cast<float*>(&lds[0][0][0]));
@@ -394,7 +440,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_mfma_kernel(const bf16* __res
 
 // ------------------------------------------------------------------------------------------ dK, dV
 template <bool FUSE>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
                                                                  const bf16* __restrict__ kh, const bf16* __restrict__ vh,
                                                                  const float* __restrict__ lse,
                                                                  const float* __restrict__ delta, float scale,
