@@ -156,14 +156,58 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
   for (int s = 0; s < total_stages; ++s) {
     if (s + NSLOT - 1 < total_stages) issue_stage();
     {
-      uint4 fa[FM], fb[4];
-      LOAD_FRAGS(fa, fb, slot, 0)
-      MMA_FRAGS(fa, fb)
-    }
-    {
-      uint4 fa[FM], fb[4];
-      LOAD_FRAGS(fa, fb, slot, 1)
-      MMA_FRAGS(fa, fb)
+      // Software-pipelined fragment stream.  The stage is 2*FM "steps" of 4 MFMAs (one A fragment against the
+      // four B fragments of its k-half).  All ds_read_b128 are written first, in the order the steps consume
+      // them; sched_group_barrier then pins the interleave: 7 reads up front (B of k-half 0 + three A), after
+      // that every step's 4 MFMAs are followed by the read(s) needed ~3 steps later, so LDS latency hides
+      // under ~12 MFMAs instead of stalling every 4 (what hipcc's own just-in-time schedule did).
+      const char* la_ = smem + slot * SLOT_BYTES;
+      const char* lb_ = la_ + A_BYTES;
+      uint4 fa[2][FM], fb[2][4];
+#define RA(kk_, i_)                                                                                       \
+  {                                                                                                       \
+    const int r = wr * WROWS + (i_) * 16 + l15;                                                           \
+    fa[kk_][i_] = *reinterpret_cast<const uint4*>(la_ + r * ROWB + ((((kk_) * 4 + lg) ^ (r & 7)) << 4));  \
+  }
+#define RB(kk_, j_)                                                                                       \
+  {                                                                                                       \
+    const int r = wc * 64 + (j_) * 16 + l15;                                                              \
+    fb[kk_][j_] = *reinterpret_cast<const uint4*>(lb_ + r * ROWB + ((((kk_) * 4 + lg) ^ (r & 7)) << 4));  \
+  }
+      __builtin_amdgcn_sched_barrier(0);
+      RB(0, 0) RB(0, 1) RB(0, 2) RB(0, 3) RA(0, 0) RA(0, 1) RA(0, 2)
+      if constexpr (FM == 8) {
+        RA(0, 3) RB(1, 0) RA(0, 4) RB(1, 1) RA(0, 5) RB(1, 2) RA(0, 6) RB(1, 3) RA(0, 7)
+        RA(1, 0) RA(1, 1) RA(1, 2) RA(1, 3) RA(1, 4) RA(1, 5) RA(1, 6) RA(1, 7)
+      } else {
+        RA(0, 3) RB(1, 0) RB(1, 1) RB(1, 2) RB(1, 3) RA(1, 0) RA(1, 1) RA(1, 2) RA(1, 3)
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) Mma<T>::run(fb[kk][j], fa[kk][i], acc[i][j]);
+      constexpr int MPS = sizeof(T) == 2 ? 4 : 16;  // MFMA instructions per step (fp32: 4 per fragment pair)
+      __builtin_amdgcn_sched_group_barrier(0x100, 7, 0);
+#pragma unroll
+      for (int t = 0; t < 2 * FM; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x8, MPS, 0);
+        if constexpr (FM == 8) {
+          if (t < 4)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          else if (t < 13)
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        } else {
+          if (t < 3)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          else if (t < 6)
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#undef RA
+#undef RB
     }
     bool stored = false;
     if (++c_k == nt) {
