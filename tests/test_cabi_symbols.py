@@ -1,0 +1,66 @@
+"""CPU: the C-ABI shared library builds (hipcc cross-compiles gfx950 without a GPU), loads, and exports every
+symbol declared in include/nvit_hip.h with the argument counts the ctypes table binds.  No compute calls."""
+import ctypes
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    h = open(os.path.join(ROOT, "include", "nvit_hip.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    out = {}
+    for name, args in re.findall(r"(?:int|void|const char\*)\s+(nvit_\w+)\s*\(([^;]*?)\)\s*;", h):
+        a = args.strip()
+        out[name] = 0 if a in ("void", "") else len(a.split(","))
+    return out
+
+
+def _lib_path():
+    from nvit_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        sys.path.insert(0, ROOT)
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.LIB_PATH
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    from nvit_amd import _lib
+    decl = _declared()
+    assert len(decl) >= 40
+    lib = ctypes.CDLL(_lib_path())
+    for name, nargs in decl.items():
+        assert hasattr(lib, name), f"{name} declared in include/nvit_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes binding"
+        assert len(_lib.SIGNATURES[name]) == nargs, f"{name}: header has {nargs} args, binding {len(_lib.SIGNATURES[name])}"
+    for name in _lib.SIGNATURES:
+        assert name in decl, f"{name} bound in _lib.py but not declared in the header"
+    assert lib.nvit_version() >= 100
+    loaded = _lib.load()
+    assert loaded.nvit_prof_name(0) == b"gemm_nt"
+
+
+def test_product_path_never_imports_the_oracle():
+    """nvit_amd/ (the product) must not import, call or link anything under oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "nvit_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert not re.search(r"(import_module|__import__)\(.*oracle", src), f
+
+
+def test_model_refuses_to_run_without_a_gpu_tensor():
+    import pytest
+    import torch
+    from nvit_amd.config import named_config
+    from nvit_amd.model import ViT
+    m = ViT(named_config("micro"))
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 32, 32))
+    from nvit_amd.train import normalize_matrices
+    with pytest.raises(RuntimeError):
+        normalize_matrices(m)

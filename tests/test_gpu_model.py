@@ -261,3 +261,45 @@ def test_block_forward_and_norm_skip_standalone_api():
     gs = blk.skip_param.grad.cpu()
     assert (gs - p["transformer.h.0.skip_param"].grad).abs().max().item() < 2e-4 * max(
         1.0, p["transformer.h.0.skip_param"].grad.abs().max().item())
+
+
+def test_base_config_full_size_properties():
+    """BASELINE config C2 (nViT-Base/16 224 px, T=784) at full model size, small batch: size-independent
+    properties instead of an oracle run — (1) samples are independent: logits of a batch equal the logits of each
+    sample alone; (2) three optimizer steps stay finite and reduce the loss on a fixed batch; (3) after every step
+    the six matrices per block have unit rows / columns; (4) fp32 mode and bf16 mode agree to bf16 tolerance."""
+    from nvit_amd.model import ViT
+    from nvit_amd.train import normalize_matrices, train_step
+    from nvit_amd.weights import load_formula_weights
+    cfg = named_config("base")
+    m = ViT(cfg)
+    load_formula_weights(m, cfg, perturb_scalars=False)
+    m = m.to("cuda:0").set_precision("bf16").train()
+    normalize_matrices(m)
+    X, y = synthetic_batch(cfg, 4)
+    X, y = X.cuda(), y.cuda()
+    with torch.no_grad():
+        m.eval()
+        full, _ = m(X)
+        singles = torch.cat([m(X[i:i + 1])[0] for i in range(4)])
+        m.set_precision("fp32")
+        full32, _ = m(X[:2])
+        m.set_precision("bf16").train()
+    assert torch.isfinite(full).all()
+    # (a batch of 4 and a batch of 1 take different kernel variants - persistent/fused vs 128-tile/unfused - so the
+    #  comparison is at bf16 tolerance, not bitwise)
+    assert (full - singles).abs().max().item() < 4e-3, "batch rows are not independent"
+    d32 = (full[:2] - full32).abs().max().item()
+    print(f"[base full size] bf16 vs fp32 mode max|dlogit| = {d32:.3e} (|logit|max {full32.abs().max().item():.3f})")
+    assert d32 < 2e-2
+    opt = m.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")
+    losses = []
+    for _ in range(3):
+        _, loss, _, gnorm = train_step(m, opt, X, y, 1.0)
+        assert torch.isfinite(loss).item() and torch.isfinite(gnorm).item()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+    for blk in m.transformer.h:
+        for lin, dim in ((blk.query, 1), (blk.key, 1), (blk.value, 1), (blk.c_fc, 1), (blk.att_c_proj, 0),
+                         (blk.mlp_c_proj, 0)):
+            assert (lin.weight.detach().norm(dim=dim) - 1).abs().max().item() < 1e-5
