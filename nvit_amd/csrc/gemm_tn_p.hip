@@ -173,37 +173,50 @@ __global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
     const char* la = smem + slot * TSLOT_BYTES;  // A tile: [m][n]  -> MFMA B operand (cols = n)
     const char* lb = la + OP_BYTES;              // B tile: [m][k'] -> MFMA A operand (rows = k')
     if constexpr (sizeof(T) == 2) {
+      // Software-pipelined fragment stream (same idea as gemm_p.hip): 16 steps of 4 MFMAs (one k' fragment of the
+      // B tile against the four n fragments of the A tile); every ds_read_b64_tr_b16 pair is written in
+      // consumption order and sched_group_barrier pins "4 MFMAs, then the reads needed ~3 steps later".
+      const int q = l15 >> 2, p = l15 & 3;
+      uint4 fa[2][4], fb[2][8];
+#define TRF(dst_, base_, ks_, col0_)                                                                              \
+  {                                                                                                               \
+    const int mrow = (ks_) * 32 + lg * 8 + q;                                                                     \
+    const int ch = ((col0_) >> 3) + (p >> 1);                                                                     \
+    const int o0 = mrow * ROW_BYTES + ((ch ^ tnp_swz(mrow)) << 4) + ((p & 1) << 3);                               \
+    const int o1 = (mrow + 4) * ROW_BYTES + ((ch ^ tnp_swz(mrow + 4)) << 4) + ((p & 1) << 3);                     \
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)((base_) + o0)); \
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)((base_) + o1)); \
+    uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);                                 \
+    dst_ = make_uint4(l2.x, l2.y, h2.x, h2.y);                                                                    \
+  }
+#define FA(ks_, j_) TRF(fa[ks_][j_], la, ks_, wc * 64 + (j_) * 16)
+#define FB(ks_, i_) TRF(fb[ks_][i_], lb, ks_, wr * 128 + (i_) * 16)
+      __builtin_amdgcn_sched_barrier(0);
+      FA(0, 0) FA(0, 1) FA(0, 2) FA(0, 3) FB(0, 0) FB(0, 1) FB(0, 2)
+      FB(0, 3)
+      FB(0, 4) FA(1, 0) FB(0, 5) FA(1, 1) FB(0, 6) FA(1, 2) FB(0, 7) FA(1, 3)
+      FB(1, 0) FB(1, 1) FB(1, 2) FB(1, 3) FB(1, 4) FB(1, 5) FB(1, 6) FB(1, 7)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int q = l15 >> 2, p = l15 & 3;
-        const int mrow = ks * 32 + lg * 8 + q;
-        const int s0 = tnp_swz(mrow), s1 = tnp_swz(mrow + 4);
-        uint4 fa[4], fb[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ch = ((wc * 64 + j * 16) >> 3) + (p >> 1);
-          const int o0 = mrow * ROW_BYTES + ((ch ^ s0) << 4) + ((p & 1) << 3);
-          const int o1 = (mrow + 4) * ROW_BYTES + ((ch ^ s1) << 4) + ((p & 1) << 3);
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(la + o0));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(la + o1));
-          uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-          fa[j] = make_uint4(l2.x, l2.y, h2.x, h2.y);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          const int ch = ((wr * 128 + i * 16) >> 3) + (p >> 1);
-          const int o0 = mrow * ROW_BYTES + ((ch ^ s0) << 4) + ((p & 1) << 3);
-          const int o1 = (mrow + 4) * ROW_BYTES + ((ch ^ s1) << 4) + ((p & 1) << 3);
-          s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lb + o0));
-          s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(lb + o1));
-          uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
-          fb[i] = make_uint4(l2.x, l2.y, h2.x, h2.y);
-        }
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) Mma<bf16>::run(fb[i], fa[j], acc[i][j]);
+          for (int j = 0; j < 4; ++j) Mma<bf16>::run(fb[ks][i], fa[ks][j], acc[i][j]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+        if (t == 0)
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        else if (t < 5)
+          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        else if (t < 13)
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#undef FA
+#undef FB
+#undef TRF
     } else {
 #pragma unroll
       for (int ks = 0; ks < RB / 4; ++ks) {
