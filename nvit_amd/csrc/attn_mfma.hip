@@ -20,6 +20,8 @@
 //               LDS); S[q][key] = Q K^T, dP = dO V^T (query-major, key on the lane),
 //               dV^T[d][key] += dO^T P, dK^T[d][key] += Q^T dS  (P/dS from accumulators, Q/dO
 //               tiles read by rows and transposed).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -175,7 +177,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
   }
   __syncthreads();
   int cur = 0;
-  for (int t = 0; t < nt; ++t) {
+  // the last tile may be ragged: only that instantiation carries the key mask (peeled, so the steady-state tiles
+  // spend no VALU on compares/selects)
+  auto tile_body = [&](const int t, auto masked_) {
+    constexpr bool MASKED = decltype(masked_)::value;
     if (t + 2 < nt) {
       const int sl = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
       tile_dma(kbase, D, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid);
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
       }
     }
     const int kbase_i = t * TKV;
-    if (kbase_i + TKV > Tk) {
+    if constexpr (MASKED) {
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
@@ -250,7 +255,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur = cur == 2 ? 0 : cur + 1;
-  }
+  };
+  for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{});
+  if (Tk % TKV)
+    tile_body(nt - 1, std::true_type{});
+  else
+    tile_body(nt - 1, std::false_type{});
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     float l = l_[f];
@@ -387,7 +397,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
   }
   __syncthreads();
   int cur = 0;
-  for (int t = 0; t < nt; ++t) {
+  auto tile_body = [&](const int t, auto masked_) {
+    constexpr bool MASKED = decltype(masked_)::value;
     if (t + 2 < nt) {
       const int sl = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
       tile_dma(kbase, D, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid);
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
           w = mfma16(v1, gf[f][1], w);  // dP^T
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const bool valid = (kbase_i + kf * 16 + lg * 4 + r) < Tk;
+            const bool valid = !MASKED || (kbase_i + kf * 16 + lg * 4 + r) < Tk;
             const float p = valid ? fast_exp2(z[r] * c2 - lse2[f]) : 0.f;
             ds_[kk][f][r] = p * (w[r] - dl[f]) * scale;
           }
@@ -439,7 +450,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur = cur == 2 ? 0 : cur + 1;
-  }
+  };
+  for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{});
+  if (Tk % TKV)
+    tile_body(nt - 1, std::true_type{});
+  else
+    tile_body(nt - 1, std::false_type{});
   if constexpr (FUSE) {
     qk_bwd_epilogue(dq, qh + (size_t)bh * Tq * D, fu, q0, Tq, H, b, h, lane, wid, reinterpret_cast<float*>(&lds[0][0][0]),
                     tile_, (Tq + 127) / 128);
