@@ -95,8 +95,15 @@ int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int ldb, void* C
  *   (model.py:148-154: the [M,8C] pre-activation is written once, never re-read in forward).
  * nvit_gemm_nt_qknorm: q/k/v projections (nparts stacked [C,K] weights starting at part part0: 0=q,1=k,2=v) with
  *   the per-head L2 normalise, sqk*c_q scale and [B,H,T,64] head split done on the fp32 accumulators
- *   (model.py:99-119); rq/rk [M,H] = 1/||.||.  Requires head dim 64 and n_embd % 256 == 0. */
+ *   (model.py:99-119); rq/rk [M,H] = 1/||.||.  Requires head dim 64 and n_embd % 256 == 0.
+ * nvit_gemm_nt_swiglu_bwd: autograd of model.py:148-155 / 259-262 in one launch: dx[M,F] = A B^T (A = dL/dy of
+ *   mlp_c_proj / out_proj, B = that weight's transposed shadow [F,K]) stays in the accumulators; with the saved raw
+ *   uv[M,2F] (interleaved, as written by nvit_gemm_nt_swiglu) it writes duv[M,2F] (same layout) and, when gs != NULL
+ *   (suv, natural order [u(F)|v(F)]), part[2*ceil(M/256), 2F] = per-128-row partial sums of d(suv) (natural order;
+ *   reduce with nvit_colsum_reduce).  Replaces nvit_gemm_nt + nvit_swiglu_bwd.  Requires F % 256 == 0. */
 int nvit_gemm_nt_fusable(int dt, int M, int N, int K);
+int nvit_gemm_nt_swiglu_bwd(int dt, const void* A, int lda, const void* B, int ldb, const void* uv, void* duv,
+                            float* part, int M, int F, int K, const float* gs, float gscale, void* stream);
 int nvit_gemm_nt_swiglu(int dt, const void* A, int lda, const void* B, int ldb, void* uv, void* xm, int M, int F,
                         int K, const float* gs, float gscale, void* stream);
 int nvit_gemm_nt_qknorm(int dt, const void* A, int lda, const void* B, int ldb, int M, int K, int nparts, int part0,

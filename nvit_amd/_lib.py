@@ -30,6 +30,7 @@ SIGNATURES = {
     "nvit_gemm_nt": [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
     "nvit_gemm_nt_fusable": [_i, _i, _i, _i],
     "nvit_gemm_nt_swiglu": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _f, _vp],
+    "nvit_gemm_nt_swiglu_bwd": [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _vp],
     "nvit_gemm_nt_qknorm": [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "nvit_gemm_tn": [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i64, _i, _i, _vp],
     "nvit_lerp_fwd": [_i, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],

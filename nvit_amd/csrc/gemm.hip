@@ -390,11 +390,11 @@ extern "C" int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int l
       const char* t = getenv("NVIT_GEMM_NT_TILE");
       force_tile = t ? atoi(t) : 0;
     }
-    if (impl == 1) {
+    if (impl >= 1) {  // 2: persistent kernel whatever the tile count (experiments)
       const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 256), t128 = (long long)cdiv(M, 256) * cdiv(N, 128);
       int tile = 0;
-      if (N % 256 == 0 && t256 >= 512) tile = 256;
-      else if (t128 >= 512) tile = 128;
+      if (N % 256 == 0 && (t256 >= 512 || impl == 2)) tile = 256;
+      else if (t128 >= 512 || impl == 2) tile = 128;
       if (force_tile && tile) tile = force_tile;
       if (tile) return nvit_gemm_nt_persistent_launch(dt, g, tile, s);
     }
@@ -504,6 +504,37 @@ extern "C" int nvit_gemm_nt_swiglu(int dt, const void* A, int lda, const void* B
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(NVIT_KID_GEMM_NT, 2.0 * M * (2.0 * F) * K, 0.0, s);
   return nvit_gemm_nt_fused_launch(g, 3, s);
+}
+
+extern "C" int nvit_gemm_nt_swiglu_bwd(int dt, const void* A, int lda, const void* B, int ldb, const void* uv,
+                                       void* duv, float* part, int M, int F, int K, const float* gs, float gscale,
+                                       void* stream) {
+  NVIT_REQUIRE(nvit_gemm_nt_fusable(dt, M, F, K), "gemm_nt_swiglu_bwd: shape/dtype not eligible for the fused kernel");
+  NVIT_REQUIRE((lda * 2) % 16 == 0 && (ldb * 2) % 16 == 0 && lda >= K && ldb >= K,
+               "gemm_nt_swiglu_bwd: bad leading dims");
+  NVIT_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)uv | (uintptr_t)duv | (uintptr_t)gs | (uintptr_t)part) & 15) == 0,
+               "gemm_nt_swiglu_bwd: pointers must be 16-byte aligned");
+  NVIT_REQUIRE(!gs || part, "gemm_nt_swiglu_bwd: part buffer missing");
+  NtArgs g{};
+  g.A = (const char*)A;
+  g.B = (const char*)B;
+  g.C = duv;
+  g.M = M;
+  g.N = F;
+  g.K = K;
+  g.lda = lda;
+  g.ldb = ldb;
+  g.ldc = 2 * F;
+  g.out_dt = NVIT_BF16;
+  g.uv_in = uv;
+  g.ld_uv = 2 * F;
+  g.Fh = F;
+  g.gs = gs;
+  g.gscale = gscale;
+  g.part = gs ? part : nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(NVIT_KID_GEMM_NT, 2.0 * M * (double)F * K, 0.0, s);
+  return nvit_gemm_nt_fused_launch(g, 5, s);
 }
 
 extern "C" int nvit_gemm_nt_qknorm(int dt, const void* A, int lda, const void* B, int ldb, int M, int K, int nparts,

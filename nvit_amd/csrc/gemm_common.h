@@ -28,6 +28,11 @@ struct NtArgs {
   const float* sqk;
   float c_q;
   int part0, Cemb, Ttok, H;
+  // --- fused SwiGLU-backward epilogue (EPI 5): acc = dx [M,Fh]; C = duv (interleaved, ldc = 2*Fh)
+  const void* uv_in;  // raw pre-activations saved by EPI 3 (interleaved u16|v16 columns), bf16
+  int ld_uv;
+  int Fh;             // hidden width F; gs = suv in natural order [u(F) | v(F)] (or NULL = ones)
+  float* part;        // [2*tiles_m, 2*Fh] column partials of d(suv) per 128-row wave tile (or NULL)
 };
 
 template <typename T>
@@ -292,4 +297,146 @@ __device__ __forceinline__ void nt_store_tile_qknorm(const NtArgs& g, f32x4 (&ac
       }
     }
   }
+}
+
+// ---- EPI 5: SwiGLU backward fused into the data-gradient GEMM of mlp_c_proj / out_proj ---------------
+// (autograd of reference model.py:148-154, 259-261).  The accumulators hold dx = dL/d(u*silu(v)) for a
+// 128x64 block of hidden columns; they are first packed to bf16 (the precision the unfused path stores dx
+// in), which frees half the accumulator registers for the rest of the epilogue.  Per 16-row x 32-column
+// piece, dx goes through the wave's LDS scratch into a row layout in which a lane owns 8 consecutive hidden
+// columns of one row; the matching raw u and v chunks (16 B each, saved by EPI 3) are streamed straight from
+// global memory through a register prefetch queue and d(uv) leaves as 16-byte stores, so uv/duv never touch
+// LDS.  Column sums of d(suv) are reduced over the wave's 128 rows and written once per wave tile (no atomics).
+template <int FMR>
+__device__ __forceinline__ void nt_store_tile_swiglu_bwd(const NtArgs& g, f32x4 (&acc)[FMR][4], int m_base,
+                                                         int n_base, int lane, char* scratch) {
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int r = lane >> 2, qd = lane & 3;  // row-layout role: row r of the piece, hidden columns [8qd, 8qd+8)
+  uint2 pk[FMR][4];
+#pragma unroll
+  for (int i = 0; i < FMR; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bf16x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) t[e] = (bf16)acc[i][j][e];
+      pk[i][j] = __builtin_bit_cast(uint2, t);
+      asm volatile("" : "+v"(pk[i][j].x), "+v"(pk[i][j].y));  // materialise here (the compiler otherwise sinks the pack)
+    }
+  __builtin_amdgcn_sched_barrier(0);  // pack first: everything below runs with the fp32 accumulators dead
+  const int ucol = 32 * (qd >> 1) + 8 * (qd & 1);  // interleaved column of this lane's u chunk inside the piece
+  const bf16* uvp = reinterpret_cast<const bf16*>(g.uv_in) + 2 * n_base + ucol;
+  bf16* dp = reinterpret_cast<bf16*>(g.C) + 2 * n_base + ucol;
+  constexpr int NH = 2 * FMR;  // pieces; hh = h * FMR + i, column half h outermost (its scales/sums stay live)
+  constexpr int PD = 6;        // prefetch depth (pieces)
+  uint4 pre[PD][2];
+  // scratch piece: 16 rows x 64 B (32 bf16 columns), 16-byte chunks XOR-swizzled by (row >> 1) & 3
+  char* wfrag = scratch + l15 * 64 + 8 * (lg & 1);
+  const int wsw = (l15 >> 1) & 3;
+  const char* rrow = scratch + r * 64 + ((qd ^ ((r >> 1) & 3)) << 4);
+#define NVIT_SWB_ISSUE(hh_, dst_)                                                        \
+  {                                                                                      \
+    int m_ = m_base + ((hh_) % FMR) * 16 + r;                                            \
+    m_ = m_ < g.M ? m_ : g.M - 1;                                                        \
+    const bf16* p_ = uvp + (size_t)m_ * g.ld_uv + 64 * ((hh_) / FMR);                    \
+    dst_[0] = *reinterpret_cast<const uint4*>(p_);                                       \
+    dst_[1] = *reinterpret_cast<const uint4*>(p_ + 16);                                  \
+  }
+#pragma unroll
+  for (int p = 0; p < PD; ++p) NVIT_SWB_ISSUE(p, pre[p]);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float gu[8], gv[8], su[8], sv[8];
+    {
+      f32x4 a0 = {1.f, 1.f, 1.f, 1.f}, a1 = a0, b0 = a0, b1 = a0;
+      if (g.gs) {
+        const float* gp = g.gs + n_base + 32 * h + 8 * qd;
+        a0 = *reinterpret_cast<const f32x4*>(gp) * g.gscale;
+        a1 = *reinterpret_cast<const f32x4*>(gp + 4) * g.gscale;
+        b0 = *reinterpret_cast<const f32x4*>(gp + g.Fh) * g.gscale;
+        b1 = *reinterpret_cast<const f32x4*>(gp + g.Fh + 4) * g.gscale;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        gu[e] = a0[e];
+        gu[e + 4] = a1[e];
+        gv[e] = b0[e];
+        gv[e + 4] = b1[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        su[e] = 0.f;
+        sv[e] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FMR; ++i) {
+      const int hh = h * FMR + i;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+        *reinterpret_cast<uint2*>(wfrag + (((2 * jj + (lg >> 1)) ^ wsw) << 4)) = pk[i][2 * h + jj];
+      const bf16x8 db = *reinterpret_cast<const bf16x8*>(rrow);
+      const bf16x8 ub = __builtin_bit_cast(bf16x8, pre[hh % PD][0]);
+      const bf16x8 vb = __builtin_bit_cast(bf16x8, pre[hh % PD][1]);
+      if (hh + PD < NH) NVIT_SWB_ISSUE(hh + PD, pre[hh % PD]);
+      const int m = m_base + i * 16 + r;
+      const float live = m < g.M ? 1.0f : 0.0f;
+      uint4 dub, dvb;  // d(uv) of this lane's 8 columns, packed bf16
+#pragma unroll
+      for (int e4 = 0; e4 < 8; e4 += 4) {
+        bf16x4 pu, pv;
+#pragma unroll
+        for (int e = e4; e < e4 + 4; ++e) {
+          const float ur = (float)ub[e], vr = (float)vb[e];
+          const float u = ur * gu[e], v = vr * gv[e];
+          const float gg = (float)db[e];
+          const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+          const float du = gg * v * sg;
+          const float dv = gg * u * sg * (1.0f + v * (1.0f - sg));
+          su[e] += du * ur * live;
+          sv[e] += dv * vr * live;
+          asm volatile("" : "+v"(su[e]), "+v"(sv[e]));  // accumulate here (else the whole chain is sunk into `if (part)`)
+          pu[e - e4] = (bf16)(du * gu[e]);
+          pv[e - e4] = (bf16)(dv * gv[e]);
+        }
+        const uint2 qu = __builtin_bit_cast(uint2, pu), qv = __builtin_bit_cast(uint2, pv);
+        if (e4 == 0) {
+          dub.x = qu.x, dub.y = qu.y, dvb.x = qv.x, dvb.y = qv.y;
+          asm volatile("" : "+v"(dub.x), "+v"(dub.y), "+v"(dvb.x), "+v"(dvb.y));  // pack now, not at the store
+        } else {
+          dub.z = qu.x, dub.w = qu.y, dvb.z = qv.x, dvb.w = qv.y;
+          asm volatile("" : "+v"(dub.z), "+v"(dub.w), "+v"(dvb.z), "+v"(dvb.w));
+        }
+        __builtin_amdgcn_sched_barrier(0);  // two groups of four columns: bounds the live temporaries
+      }
+      if (m < g.M) {
+        bf16* o_ = dp + (size_t)m * g.ldc + 64 * h;
+        *reinterpret_cast<uint4*>(o_) = dub;
+        *reinterpret_cast<uint4*>(o_ + 16) = dvb;
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch queue PD deep (no hoisting of later pieces' loads)
+    }
+    if (g.part) {
+      // sum over the 16 row lanes that share qd (fixed order); lanes r == 0 write 8 consecutive columns
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float a = su[e], b = sv[e];
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) {
+          a += __shfl_xor(a, o, 64);
+          b += __shfl_xor(b, o, 64);
+        }
+        su[e] = a * g.gscale;
+        sv[e] = b * g.gscale;
+      }
+      if (r == 0) {
+        float* pp = g.part + (size_t)(m_base >> 7) * (2 * g.Fh) + n_base + 32 * h + 8 * qd;
+        *reinterpret_cast<f32x4*>(pp) = (f32x4){su[0], su[1], su[2], su[3]};
+        *reinterpret_cast<f32x4*>(pp + 4) = (f32x4){su[4], su[5], su[6], su[7]};
+        *reinterpret_cast<f32x4*>(pp + g.Fh) = (f32x4){sv[0], sv[1], sv[2], sv[3]};
+        *reinterpret_cast<f32x4*>(pp + g.Fh + 4) = (f32x4){sv[4], sv[5], sv[6], sv[7]};
+      }
+    }
+  }
+#undef NVIT_SWB_ISSUE
 }

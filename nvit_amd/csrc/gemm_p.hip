@@ -31,15 +31,12 @@ struct PCfg<8> {  // 256 x 256
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 6 || N == 8 || N == 12, "unsupported vmcnt");
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 // EPI: 0 = generic direct epilogue, 1 = LDS-staged bf16 output, 2 = LDS-staged fp32 output,
-//      3 = fused SwiGLU (bf16), 4 = fused q/k-normalise + head split (bf16)
+//      3 = fused SwiGLU (bf16), 4 = fused q/k-normalise + head split (bf16), 5 = fused SwiGLU backward (bf16)
 template <typename T, int FM, int EPI>
 __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int tiles_m, int ntiles) {
   using Cfg = PCfg<FM>;
@@ -47,6 +44,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
   constexpr int A_BYTES = PBM * ROWB, B_BYTES = PBN * ROWB, SLOT_BYTES = A_BYTES + B_BYTES;
   constexpr int DPS = Cfg::A_DMA + Cfg::B_DMA;  // DMA wave-instructions per wave per stage
   constexpr int WROWS = 16 * FM;                // rows of a wave's sub-tile
+  // global stores one wave issues in the epilogue of a tile that lies fully inside C (lower bound; 0 = unknown)
+  constexpr int NST = EPI == 1 ? 2 * FM : EPI == 2 ? 4 * FM : EPI == 3 ? 3 * FM : EPI == 4 ? 2 * FM : EPI == 5 ? 8 : 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int EPC = 16 / sizeof(T);
   constexpr int BK = ROWB / sizeof(T);
@@ -209,10 +208,11 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
 #undef RA
 #undef RB
     }
-    bool stored = false;
+    bool stored = false, full_tile = false;
     if (++c_k == nt) {
       int m0, n0;
       tile_of(c_it, m0, n0);
+      full_tile = NST > 0 && m0 + PBM <= g.M && n0 + PBN <= g.N;
       {
         char* scratch = smem + NSLOT * SLOT_BYTES + wid * 2048;
         if constexpr (EPI == 1)
@@ -223,6 +223,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
           nt_store_tile_swiglu<FM>(g, acc, m0 + wr * WROWS, n0 + wc * 64, lane, scratch);
         else if constexpr (EPI == 4)
           nt_store_tile_qknorm<FM>(g, acc, m0 + wr * WROWS, n0 + wc * 64, lane, scratch);
+        else if constexpr (EPI == 5)
+          nt_store_tile_swiglu_bwd<FM>(g, acc, m0 + wr * WROWS, n0 + wc * 64, lane, scratch);
         else
           nt_store_tile<FM>(g, acc, m0 + wr * WROWS, n0 + wc * 64, l15, lg);
       }
@@ -234,11 +236,20 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
       ++c_it;
       stored = true;
     }
-    // retire DMA(s+1).  vmcnt counts stores too (issue order): after an epilogue drain everything.
-    if (NSLOT > 2 && s + 2 < total_stages && !stored)
+    // retire DMA(s+1).  vmcnt counts stores too, in issue order, and the epilogue's stores are younger than
+    // every DMA issued so far: after a full tile (a known number of store instructions per wave) wait only
+    // for what is older than them, so the write-back drains under the next tile's first stage instead of
+    // stalling the whole workgroup on HBM write acknowledgements.
+    if (stored) {
+      if (full_tile && s + NSLOT - 1 < total_stages)
+        wait_vmcnt<(NSLOT - 2) * DPS + NST>();
+      else
+        wait_vmcnt<0>();
+    } else if (NSLOT > 2 && s + 2 < total_stages) {
       wait_vmcnt<(NSLOT > 2 ? (NSLOT - 2) * DPS : 0)>();
-    else
+    } else {
       wait_vmcnt<0>();
+    }
     __syncthreads();
     slot = slot == NSLOT - 1 ? 0 : slot + 1;
   }
@@ -269,7 +280,8 @@ int launch_p2(const NtArgs& g_in, int n_cu, hipStream_t s) {
 template <typename T, int FM>
 int launch_p(const NtArgs& g, int n_cu, hipStream_t s) {
   const int eo = g.out_dt == NVIT_F32 ? 4 : 8;  // output elements per 16-byte chunk
-  const bool staged = (g.N % eo) == 0 && (g.ldc % eo) == 0;
+  static const bool no_stage = getenv("NVIT_GEMM_DIRECT") != nullptr;  // experiments
+  const bool staged = (g.N % eo) == 0 && (g.ldc % eo) == 0 && !no_stage;
   if (!staged) return launch_p2<T, FM, 0>(g, n_cu, s);
   return g.out_dt == NVIT_F32 ? launch_p2<T, FM, 2>(g, n_cu, s) : launch_p2<T, FM, 1>(g, n_cu, s);
 }
@@ -289,10 +301,11 @@ static int p_num_cu() {
   return n_cu;
 }
 
-// fused-epilogue launches (bf16 operands, 256x256 tiles): epi = 3 (SwiGLU) or 4 (q/k normalise)
+// fused-epilogue launches (bf16 operands, 256x256 tiles): epi = 3 (SwiGLU), 4 (q/k normalise), 5 (SwiGLU backward)
 int nvit_gemm_nt_fused_launch(const NtArgs& g, int epi, hipStream_t s) {
   const int n_cu = p_num_cu();
   if (n_cu == 0) NVIT_FAIL(NVIT_EINVAL, "gemm_nt: cannot query device properties");
+  if (epi == 5) return launch_p2<bf16, 8, 5>(g, n_cu, s);
   return epi == 3 ? launch_p2<bf16, 8, 3>(g, n_cu, s) : launch_p2<bf16, 8, 4>(g, n_cu, s);
 }
 
@@ -307,6 +320,7 @@ int nvit_gemm_nt_persistent_launch(int dt, const NtArgs& g, int tile_n, hipStrea
     n_cu = prop.multiProcessorCount;
     n_cu -= n_cu % 8;
     if (n_cu < 8) n_cu = 8;
+    if (const char* e = getenv("NVIT_GEMM_CUS")) n_cu = atoi(e);  // experiments: restrict the persistent grid
   }
   if (dt == NVIT_BF16) return tile_n == 256 ? launch_p<bf16, 8>(g, n_cu, s) : launch_p<bf16, 4>(g, n_cu, s);
   return tile_n == 256 ? launch_p<float, 8>(g, n_cu, s) : launch_p<float, 4>(g, n_cu, s);

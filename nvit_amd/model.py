@@ -292,12 +292,16 @@ class _BlockFn(torch.autograd.Function):
                                                           False, True)
             dx, dskip = None, None
         d_mlp_alpha = _param_grad_alpha(part_lam, mlp_alpha, c_a)
-        dxm = ops.gemm_nt(dy2_lo, sh[pre + "p.Wt"], M, 4 * C, C, out_dtype=td)
+        gscale = math.sqrt(C)
+        if ops.fusable(dt, M, 4 * C, C):
+            # data gradient of mlp_c_proj with the SwiGLU backward in the GEMM epilogue (dx_mlp never reaches HBM)
+            duv, part_suv = ops.gemm_nt_swiglu_bwd(dy2_lo, sh[pre + "p.Wt"], uv, M, 4 * C, C, suv, gscale)
+        else:
+            dxm = ops.gemm_nt(dy2_lo, sh[pre + "p.Wt"], M, 4 * C, C, out_dtype=td)
+            duv, part_suv = ops.swiglu_bwd(dt, dxm, uv, suv, gscale, M, 4 * C)
         g_wp = torch.empty((C, 4 * C), device=x.device, dtype=torch.float32)
         rt.on_side(lambda: ops.gemm_tn(dy2_lo, xm, g_wp, M, C, 4 * C), dy2_lo, xm)
         g_bp = _bias_grad(dy2_lo, M, C) if ctx.has_b else None
-        gscale = math.sqrt(C)
-        duv, part_suv = ops.swiglu_bwd(dt, dxm, uv, suv, gscale, M, 4 * C)
         d_suv = _param_grad_scaled(part_suv, suv, 1.0)
         ops.gemm_nt(duv, sh[pre + "fc.Wt"], M, C, 8 * C, out=dh1, accumulate=True)
         g_wfc = torch.empty((8 * C, C), device=x.device, dtype=torch.float32)
@@ -399,10 +403,13 @@ class _CrossFn(torch.autograd.Function):
         dloc, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dx.contiguous(), loc, y, attn_alpha, c_a, None, None, None,
                                                       False, False, True)
         d_alpha = _param_grad_alpha(part_lam, attn_alpha, c_a)
-        dg = ops.gemm_nt(dy_lo, sh["x.out.Wt"], M, C, C, out_dtype=td)
+        if ops.fusable(dt, M, C, C):
+            dpr, _ = ops.gemm_nt_swiglu_bwd(dy_lo, sh["x.out.Wt"], pr, M, C, C, None, 1.0)
+        else:
+            dg = ops.gemm_nt(dy_lo, sh["x.out.Wt"], M, C, C, out_dtype=td)
+            dpr, _ = ops.swiglu_bwd(dt, dg, pr, None, 1.0, M, C)
         g_wout = ops.gemm_tn(dy_lo, g, torch.empty((C, C), device=dev, dtype=torch.float32), M, C, C)
         g_bout = _bias_grad(dy_lo, M, C) if ctx.has_b else None
-        dpr, _ = ops.swiglu_bwd(dt, dg, pr, None, 1.0, M, C)
         do = ops.gemm_nt(dpr, sh["x.proj.Wt"], M, C, 2 * C, out_dtype=td)
         g_wproj = ops.gemm_tn(dpr, o, torch.empty((2 * C, C), device=dev, dtype=torch.float32), M, 2 * C, C, perm=1)
         g_bproj = _bias_grad(dpr, M, 2 * C, perm=1) if ctx.has_b else None

@@ -90,6 +90,17 @@ def gemm_nt_swiglu(A: Tensor, B: Tensor, M: int, F: int, K: int, gs: Optional[Te
     return uv, xm
 
 
+def gemm_nt_swiglu_bwd(A: Tensor, B: Tensor, uv: Tensor, M: int, F: int, K: int, gs: Optional[Tensor], gscale: float):
+    """duv [M,2F] (interleaved) and the d(suv) partials from dy [M,K] and W^T [F,K] in one launch (bf16)."""
+    _chk_dev(A, B, uv)
+    duv = torch.empty((M, 2 * F), device=A.device, dtype=torch.bfloat16)
+    part = (torch.empty((2 * math.ceil(M / 256), 2 * F), device=A.device, dtype=torch.float32)
+            if gs is not None else None)
+    check(_lib.load().nvit_gemm_nt_swiglu_bwd(dt_of(A), _p(A), A.stride(0), _p(B), B.stride(0), _p(uv), _p(duv),
+                                              _p(part), M, F, K, _p(gs), gscale, _s()), "nvit_gemm_nt_swiglu_bwd")
+    return duv, part
+
+
 def qk_buffers(dt: int, B: int, T: int, H: int, d: int, device):
     td = tdtype(dt)
     qh = torch.empty((B, H, T, d), device=device, dtype=td)

@@ -345,3 +345,33 @@ def test_fused_gemm_swiglu_and_qknorm_match_unfused():
     assert (vh.float() - acc[2]).abs().max().item() < 2e-2 * acc[2].abs().max().item()
     rq_ref = (1.0 / acc[0].norm(dim=-1)).permute(0, 2, 1).reshape(M, H)
     assert (rq - rq_ref).abs().max().item() < 1e-3 * rq_ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,use_suv", [(6000, True), (5123, True), (6000, False)])
+def test_fused_gemm_swiglu_bwd_matches_unfused(M, use_suv):
+    """Data-gradient GEMM with the SwiGLU backward in its epilogue vs nvit_gemm_nt + nvit_swiglu_bwd (ragged M too)."""
+    ops = ops_()
+    from nvit_amd._lib import BF16
+    d_ = dev()
+    F, K = 1024, 256
+    dy = rnd(M, K, seed=11).bfloat16().to(d_)
+    Wt = (rnd(F, K, seed=12) * 0.05).bfloat16().to(d_)          # transposed shadow of the [K, F] projection
+    uv = rnd(M, 2 * F, seed=13).bfloat16().to(d_)                 # saved raw pre-activations (interleaved)
+    suv = (rnd(2 * F, seed=14, scale=0.1) + 1).to(d_) if use_suv else None
+    gscale = 1.7 if use_suv else 1.0
+    assert ops.fusable(BF16, M, F, K)
+    duv, part = ops.gemm_nt_swiglu_bwd(dy, Wt, uv, M, F, K, suv, gscale)
+    dx = ops.gemm_nt(dy, Wt, M, F, K, out_dtype=torch.bfloat16)
+    duv_ref, part_ref = ops.swiglu_bwd(BF16, dx, uv, suv, gscale, M, F)
+    err = (duv.float() - duv_ref.float()).abs().max().item()
+    assert err <= 2e-2 * max(1.0, duv_ref.float().abs().max().item()), err
+    # tighter: mean error (both paths round dx to bf16 first, so they differ only by exp/rcp ulps)
+    assert (duv.float() - duv_ref.float()).abs().mean().item() < 1e-3
+    if use_suv:
+        g = torch.empty(2 * F, device=d_)
+        g_ref = torch.empty(2 * F, device=d_)
+        ops.colsum_reduce(part, g, False)
+        ops.colsum_reduce(part_ref, g_ref, False)
+        assert (g - g_ref).abs().max().item() <= 2e-3 * g_ref.abs().max().item()
+    else:
+        assert part is None

@@ -14,20 +14,25 @@ def bench(fn, flops, iters=20):
     ms = a.elapsed_time(b) / iters
     return ms, flops / ms / 1e9
 
-M = 100352
-dev = "cuda:0"
-for (N, K, name) in [(768, 768, "o / o.Wt"), (2304, 768, "qkv"), (6144, 768, "fc"), (768, 3072, "p"),
-                     (3072, 768, "p.Wt"), (768, 6144, "fc.Wt"), (768, 2304, "qkv.Wt")]:
-    A = torch.randn(M, K, device=dev).bfloat16()
-    B = torch.randn(N, K, device=dev).bfloat16()
-    out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-    ms, tf = bench(lambda: ops.gemm_nt(A, B, M, N, K, out=out), 2.0 * M * N * K)
-    out32 = torch.empty(M, N, device=dev, dtype=torch.float32)
-    ms2, tf2 = bench(lambda: ops.gemm_nt(A, B, M, N, K, out=out32), 2.0 * M * N * K)
-    print(f"NT {name:8s} N={N:5d} K={K:5d}: bf16-out {ms:7.3f} ms {tf:7.1f} TF/s | f32-out {ms2:7.3f} ms {tf2:7.1f} TF/s")
-for (N, K, name) in [(768, 768, "o"), (2304, 768, "qkv"), (6144, 768, "fc"), (768, 3072, "p")]:
-    A = torch.randn(M, N, device=dev).bfloat16()
-    B = torch.randn(M, K, device=dev).bfloat16()
-    G = torch.empty(N, K, device=dev)
-    ms, tf = bench(lambda: ops.gemm_tn(A, B, G, M, N, K), 2.0 * M * N * K)
-    print(f"TN {name:8s} N={N:5d} K={K:5d}: {ms:7.3f} ms {tf:7.1f} TF/s  splits={ops.tn_splits(M, N, K, 1)}")
+def main():
+    M = 100352
+    dev = "cuda:0"
+    for (N, K, name) in [(768, 768, "o / o.Wt"), (2304, 768, "qkv"), (6144, 768, "fc"), (768, 3072, "p"),
+                         (3072, 768, "p.Wt"), (768, 6144, "fc.Wt"), (768, 2304, "qkv.Wt")]:
+        A = torch.randn(M, K, device=dev).bfloat16()
+        B = torch.randn(N, K, device=dev).bfloat16()
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        ms, tf = bench(lambda: ops.gemm_nt(A, B, M, N, K, out=out), 2.0 * M * N * K)
+        out32 = torch.empty(M, N, device=dev, dtype=torch.float32)
+        ms2, tf2 = bench(lambda: ops.gemm_nt(A, B, M, N, K, out=out32), 2.0 * M * N * K)
+        print(f"NT {name:8s} N={N:5d} K={K:5d}: bf16-out {ms:7.3f} ms {tf:7.1f} TF/s | f32-out {ms2:7.3f} ms {tf2:7.1f} TF/s")
+    for (N, K, name) in [(768, 768, "o"), (2304, 768, "qkv"), (6144, 768, "fc"), (768, 3072, "p")]:
+        A = torch.randn(M, N, device=dev).bfloat16()
+        B = torch.randn(M, K, device=dev).bfloat16()
+        G = torch.empty(N, K, device=dev)
+        ms, tf = bench(lambda: ops.gemm_tn(A, B, G, M, N, K), 2.0 * M * N * K)
+        print(f"TN {name:8s} N={N:5d} K={K:5d}: {ms:7.3f} ms {tf:7.1f} TF/s  splits={ops.tn_splits(M, N, K, 1)}")
+
+
+if __name__ == "__main__":
+    main()
