@@ -79,6 +79,22 @@ int nvit_renorm_weights(const int64_t* table, int n, int total_items, void* stre
  * Element type of dst/dstT is `dt`. */
 int nvit_shadow_weights(const int64_t* table, int n, int total_items, int dt, void* stream);
 
+/* Optimizer step fused with the re-normalisation: replaces clip_grad_norm_ + AdamW.step +
+ * Trainer.normalize_matrices (train.py:935-946, 461-480, 989-990; parameter groups of model.py:369-385).
+ * table: n rows of 10 int64 {p, g, m, v (fp32 device pointers), rows, cols, kind, first_item, first_chunk,
+ *        f32bits(lr) | f32bits(weight_decay) << 32};  kind -1 = plain (items of 8192 elements), 1 = normalise rows
+ *        (items of 16 rows; cols % 4 == 0, cols <= 1536), 0 = normalise columns (items of 32 columns, rows <= 1152);
+ *        first_chunk counts 8192-element chunks of the gradient for nvit_grad_sqnorm.
+ * nvit_grad_sqnorm: partial[npart] = per-workgroup sums of g*g over all gradients (npart <= 4096 workgroups).
+ * nvit_adamw_renorm: clip = min(1, max_norm / (sqrt(sum partial) + 1e-6)) when partial != NULL and max_norm > 0;
+ *        g *= clip; torch AdamW update (decoupled decay, bias corrections 1 - beta^t passed by the host); rows /
+ *        columns of kind 1 / 0 matrices are L2-normalised before the single write-back.  gnorm_out[0] (optional)
+ *        receives the pre-clip global gradient norm.  max_slab_rows = largest `rows` among kind-0 entries. */
+int nvit_grad_sqnorm(const int64_t* table, int n, int total_chunks, float* partial, int npart, void* stream);
+int nvit_adamw_renorm(const int64_t* table, int n, int total_items, int max_slab_rows, float beta1, float beta2,
+                      float eps, double bias_correction1, double bias_correction2, const float* partial, int npart,
+                      float max_norm, float* gnorm_out, void* stream);
+
 /* ---- GEMMs ------------------------------------------------------------------------
  * nvit_gemm_nt: C[M,N] = A[M,K] * B[N,K]^T  (nn.Linear: model.py:99-101,130,148,155,...)
  * A, B of type dt, K % (128/sizeof(dt)) == 0, lda/ldb multiples of 16 bytes.

@@ -10,4 +10,7 @@ def __getattr__(name):
     if name in ("normalize_matrices", "train_step"):
         from . import train
         return getattr(train, name)
+    if name == "FusedAdamW":
+        from . import optim
+        return optim.FusedAdamW
     raise AttributeError(name)

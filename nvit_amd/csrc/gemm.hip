@@ -22,6 +22,7 @@
 
 int nvit_gemm_nt_persistent_launch(int dt, const NtArgs& g, int tile_n, hipStream_t s);
 int nvit_gemm_nt_fused_launch(const NtArgs& g, int epi, hipStream_t s);
+
 int nvit_gemm_tn_persistent_launch(int dt, const void* A, int lda, const void* B, int ldb, float* ws,
                                    const float* zeros, int Mred, int N, int K, int splits, hipStream_t s);
 

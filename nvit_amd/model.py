@@ -761,14 +761,19 @@ class ViT(nn.Module):
     # ---- reference API
     def configure_optimizers(self, weight_decay: float, learning_rate: float, betas: Tuple[float, float],
                              device_type: str) -> torch.optim.AdamW:
-        """Same parameter groups as reference model.py:369-385 (nViT branch); torch's AdamW (out of scope, F1)."""
+        """Same parameter groups as reference model.py:369-385 (nViT branch).  On the HIP device the optimizer is
+        FusedAdamW (torch.optim.AdamW subclass, same state_dict); the torch class is only returned for a CPU-resident
+        model, which cannot run forward anyway (no CPU path)."""
         pd = {n: p for n, p in self.named_parameters() if p.requires_grad}
         groups = [
             {"params": [p for n, p in pd.items() if "sz" not in n and p.dim() >= 2], "weight_decay": weight_decay},
             {"params": [p for n, p in pd.items() if "sz" not in n and p.dim() < 2], "weight_decay": 0.0},
             {"params": [self.sz], "weight_decay": 0.0},
         ]
-        return torch.optim.AdamW(groups, lr=learning_rate, betas=betas, fused=(device_type == "cuda"))
+        if device_type == "cuda":
+            from .optim import FusedAdamW  # a torch.optim.AdamW whose step runs as nvit_adamw_renorm (SURVEY §8f F1)
+            return FusedAdamW(groups, lr=learning_rate, betas=betas)
+        return torch.optim.AdamW(groups, lr=learning_rate, betas=betas)
 
     def estimate_mfu(self, fwdbwd_per_iter: int, dt: float) -> Tuple[float, float]:
         """Reference formula (model.py:387-401): 6N + 12LHQT per token against the A100 constant 312e12."""

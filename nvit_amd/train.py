@@ -6,8 +6,9 @@ place — but ONE persistent HIP launch instead of ~30 torch kernels per block.
 
 `train_step` reproduces the call sequence of the reference hot loop
 (train.py:898-946,989-990): forward -> cross_entropy -> backward -> clip_grad_norm_(1.0) ->
-AdamW.step -> zero_grad(set_to_none) -> normalize_matrices.  Cross-entropy, clipping and AdamW
-stay torch operators on the ROCm device (out of scope).
+AdamW.step -> zero_grad(set_to_none) -> normalize_matrices.  With the FusedAdamW that
+`configure_optimizers` returns, clip + AdamW + renorm run as two HIP launches (optim.py, SURVEY.md §8f F1);
+with a plain torch optimizer the three steps run separately, same result.
 """
 from __future__ import annotations
 
@@ -17,6 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ops
+from .optim import FusedAdamW
 
 _RENORM_ROWS = ("query", "key", "value", "c_fc")     # dim=1
 _RENORM_COLS = ("att_c_proj", "mlp_c_proj")          # dim=0
@@ -70,9 +72,16 @@ def train_step(model, optimizer, X: torch.Tensor, y: torch.Tensor, grad_clip: fl
     loss.backward()
     if sync_grads is not None:
         sync_grads()
-    params = [p for p in _unwrap(model).parameters() if p.grad is not None]
-    gnorm = torch.nn.utils.clip_grad_norm_(params, grad_clip) if grad_clip != 0.0 else None
-    optimizer.step()
-    optimizer.zero_grad(set_to_none=True)
-    normalize_matrices(model)
+    if isinstance(optimizer, FusedAdamW):
+        # clip + AdamW + normalize_matrices in two launches (nvit_grad_sqnorm, nvit_adamw_renorm)
+        gnorm = optimizer.step_fused(model, grad_clip)
+        if gnorm is not None:
+            gnorm = gnorm[0].clone()
+        optimizer.zero_grad(set_to_none=True)
+    else:
+        params = [p for p in _unwrap(model).parameters() if p.grad is not None]
+        gnorm = torch.nn.utils.clip_grad_norm_(params, grad_clip) if grad_clip != 0.0 else None
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+        normalize_matrices(model)
     return logits.detach(), loss.detach(), aux, gnorm

@@ -375,3 +375,64 @@ def test_fused_gemm_swiglu_bwd_matches_unfused(M, use_suv):
         assert (g - g_ref).abs().max().item() <= 2e-3 * g_ref.abs().max().item()
     else:
         assert part is None
+
+
+@pytest.mark.parametrize("grad_clip", [0.0, 0.05])
+def test_fused_adamw_renorm_matches_torch(grad_clip):
+    """FusedAdamW.step_fused (clip + AdamW + row/column renorm in two launches) against the reference sequence
+    clip_grad_norm_ -> torch.optim.AdamW.step -> x / ||x|| (train.py:935-946, 461-480) on CPU fp32, three steps."""
+    from nvit_amd.optim import FusedAdamW
+    d_ = dev()
+    shapes = [((40, 768), 1), ((768, 40), 0), ((100, 260), 1), ((1000, 100), 0), ((517,), -1), ((30, 33), -1),
+              ((8192 * 2 + 12,), -1), ((3, 5, 8, 8), -1)]
+    ref = [torch.nn.Parameter(rnd(*s, seed=20 + i, scale=0.05)) for i, (s, _) in enumerate(shapes)]
+    mine = [torch.nn.Parameter(p.detach().clone().to(d_)) for p in ref]
+    groups = lambda ps: [{"params": [p for p in ps if p.dim() >= 2], "weight_decay": 0.1},
+                         {"params": [p for p in ps if p.dim() < 2], "weight_decay": 0.0}]
+    o_ref = torch.optim.AdamW(groups(ref), lr=1e-2, betas=(0.9, 0.95))
+    o_my = FusedAdamW(groups(mine), lr=1e-2, betas=(0.9, 0.95))
+    dims = {id(p): k for p, (_, k) in zip(mine, shapes) if k >= 0}
+    for step in range(3):
+        for i, (pr, pm) in enumerate(zip(ref, mine)):
+            g = rnd(*pr.shape, seed=100 + 10 * step + i, scale=0.02)
+            pr.grad = g.clone()
+            pm.grad = g.to(d_)
+        if grad_clip > 0:
+            gn_ref = torch.nn.utils.clip_grad_norm_(ref, grad_clip)
+        o_ref.step()
+        with torch.no_grad():
+            for pr, (_, k) in zip(ref, shapes):
+                if k == 1:
+                    pr.copy_(pr / pr.norm(dim=1, keepdim=True))
+                elif k == 0:
+                    pr.copy_(pr / pr.norm(dim=0, keepdim=True))
+        gn = _step_with_dims(o_my, dims, grad_clip)
+        if grad_clip > 0:
+            assert abs(gn.item() - gn_ref.item()) <= 1e-5 * gn_ref.item()
+        for pr, pm in zip(ref, mine):
+            err = (pm.detach().cpu() - pr.detach()).abs().max().item()
+            assert err <= 2e-6 * max(1.0, pr.detach().abs().max().item()), (step, tuple(pr.shape), err)
+    # optimizer state matches torch's layout and values
+    sd_ref, sd_my = o_ref.state_dict(), o_my.state_dict()
+    assert sd_ref["state"].keys() == sd_my["state"].keys()
+    for k in sd_ref["state"]:
+        assert float(sd_my["state"][k]["step"]) == float(sd_ref["state"][k]["step"]) == 3.0
+        for name in ("exp_avg", "exp_avg_sq"):
+            a, b = sd_my["state"][k][name].cpu(), sd_ref["state"][k][name]
+            assert (a - b).abs().max().item() <= 1e-6 * max(1e-3, b.abs().max().item())
+
+
+def _step_with_dims(opt, dims, grad_clip):
+    """FusedAdamW.step_fused with a hand-made renorm map (the public method builds it from ViT blocks)."""
+    import types
+    m = types.SimpleNamespace()
+    m.config = types.SimpleNamespace(use_nvit=True)
+    rows = [p for g in opt.param_groups for p in g["params"] if dims.get(id(p)) == 1]
+    cols = [p for g in opt.param_groups for p in g["params"] if dims.get(id(p)) == 0]
+    # pack the matrices into fake blocks: 4 row-normalised + 2 column-normalised slots each, padding with repeats
+    blk = types.SimpleNamespace()
+    W = lambda p: types.SimpleNamespace(weight=p)
+    blk.query, blk.key, blk.value, blk.c_fc = W(rows[0]), W(rows[1]), W(rows[0]), W(rows[1])
+    blk.att_c_proj, blk.mlp_c_proj = W(cols[0]), W(cols[1])
+    m.transformer = types.SimpleNamespace(h=[blk])
+    return opt.step_fused(m, grad_clip)
