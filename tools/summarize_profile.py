@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def short(name):
     for key in ("gemm_nt_persistent", "gemm_tn_persistent", "gemm_nt_kernel", "gemm_tn_kernel", "attn_fwd_mfma",
                 "attn_bwd_dq_mfma", "attn_bwd_dkv_mfma", "attn_delta", "lerp_fwd", "lerp_bwd", "qknorm_fwd",
-                "qknorm_bwd", "swiglu_fwd", "swiglu_bwd", "colsum_reduce", "colsum_kernel", "slab_reduce", "renorm",
+                "qknorm_bwd", "swiglu_fwd", "swiglu_bwd", "colsum_reduce", "colsum_kernel", "slab_reduce", "adamw_renorm", "grad_sqnorm", "renorm",
                 "shadow", "im2col", "pool", "recon", "cast_kernel", "scale_cols", "FusedAdam", "multi_tensor",
                 "elementwise", "rocclr", "reduce_kernel", "softmax", "nll_loss"):
         if key in name:
@@ -26,6 +26,47 @@ def short(name):
                 return f"gemm_nt_persistent<FM={m.group(1)},EPI={m.group(2)}>" if m else key
             return key
     return name[:60]
+
+
+def _db(d):
+    """rocprofv3 writes either CSV files or one rocpd SQLite database, depending on its default output format."""
+    f = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    return f[0] if f else None
+
+
+def kernel_stats(d):
+    """Rows {Name, Calls, TotalDurationNs, AverageNs, Percentage, MinNs, MaxNs}, longest total first."""
+    f = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    if f:
+        return list(csv.DictReader(open(f[0])))
+    import sqlite3
+    c = sqlite3.connect(_db(d))
+    agg = collections.OrderedDict()
+    for name, dur in c.execute("select name, duration from kernels"):
+        a = agg.setdefault(name, [0, 0, 1 << 62, 0])
+        a[0] += 1
+        a[1] += dur
+        a[2] = min(a[2], dur)
+        a[3] = max(a[3], dur)
+    tot = sum(a[1] for a in agg.values()) or 1
+    rows = [{"Name": n, "Calls": a[0], "TotalDurationNs": a[1], "AverageNs": round(a[1] / a[0], 6),
+             "Percentage": round(100.0 * a[1] / tot, 4), "MinNs": a[2], "MaxNs": a[3]} for n, a in agg.items()]
+    rows.sort(key=lambda r: -r["TotalDurationNs"])
+    return rows
+
+
+def counter_rows(d, counter):
+    """(kernel name, counter value summed over its instances) per dispatch."""
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            yield r["Kernel_Name"], float(r["Counter_Value"])
+        return
+    import sqlite3
+    c = sqlite3.connect(_db(d))
+    q = "select dispatch_id, kernel_name, sum(value) from counters_collection where counter_name = ? group by dispatch_id, kernel_name"
+    for _, name, value in c.execute(q, (counter,)):
+        yield name, float(value)
 
 
 def main():
@@ -39,8 +80,7 @@ def main():
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     if a.trace:
-        f = glob.glob(os.path.join(a.trace, "*", "*kernel_stats.csv"))[0]
-        rows = list(csv.DictReader(open(f)))
+        rows = kernel_stats(a.trace)
         with open(os.path.join(out, f"{a.tag}_kernel_stats.csv"), "w") as w:
             w.write(f"# rocprofv3 --kernel-trace --stats -- {a.cmd}\n")
             cw = csv.writer(w)
@@ -52,12 +92,11 @@ def main():
     for kind, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
         if not d:
             continue
-        f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
         agg = collections.defaultdict(lambda: [0, 0.0])
-        for r in csv.DictReader(open(f)):
-            k = short(r["Kernel_Name"])
+        for name, value in counter_rows(d, kind):
+            k = short(name)
             agg[k][0] += 1
-            agg[k][1] += float(r["Counter_Value"])
+            agg[k][1] += value
         pm[kind] = agg
     if pm:
         names = sorted(set().union(*[set(v) for v in pm.values()]))
