@@ -267,6 +267,7 @@ class _BlockFn(torch.autograd.Function):
         ctx.save_for_backward(x, x_lo, qh, kh, vh, rq, rk, o, lse, y, h1, h1_lo, uv, xm, y2, skip_param, attn_alpha,
                               mlp_alpha, sqk, suv)
         ctx.mark_non_differentiable(xn_lo)
+        ctx.set_materialize_grads(False)  # no zero-filled [M,C] gradient for the bf16 twin on every backward
         return xn, xn_lo
 
     @staticmethod
@@ -280,6 +281,8 @@ class _BlockFn(torch.autograd.Function):
         sh = rt.sh
         c_q, c_a = 1.0 / cfg.base_scale, 0.05 / cfg.base_scale
         pre = f"h{idx}."
+        if dxn is None:
+            return (None,) * 23
         dxn = dxn.contiguous()
         # ---- MLP half + norm_skip
         if ctx.with_skip:
@@ -388,10 +391,13 @@ class _CrossFn(torch.autograd.Function):
         ctx.dims = (B, T, C, H, d, M)
         ctx.save_for_backward(loc, glo, loc_lo, glo_lo, qh, kh, vh, rq, rk, o, lse, pr, g, y, attn_alpha, sqk)
         ctx.mark_non_differentiable(x_lo)
+        ctx.set_materialize_grads(False)
         return x, x_lo
 
     @staticmethod
     def backward(ctx, dx, _unused):
+        if dx is None:
+            return (None,) * 16
         loc, glo, loc_lo, glo_lo, qh, kh, vh, rq, rk, o, lse, pr, g, y, attn_alpha, sqk = ctx.saved_tensors
         rt, impl = ctx.rt, ctx.impl
         B, T, C, H, d, M = ctx.dims
