@@ -76,13 +76,16 @@ def main() -> None:
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: all ranks use cuda:0 (needs --backend gloo); not a valid benchmark")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one hipGraph (1 GPU, no Kohonen head); the per-kernel roofline is then "
+                         "taken from a short eager pass after the timed region")
     args = ap.parse_args()
 
     import torch.distributed as dist
     from nvit_amd import ops
     from nvit_amd.config import named_config, train_flops_per_image
     from nvit_amd.model import ViT
-    from nvit_amd.train import normalize_matrices, train_step
+    from nvit_amd.train import GraphedTrainStep, normalize_matrices, train_step
     from nvit_amd.weights import formula_state_dict, load_formula_weights, synthetic_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -125,13 +128,32 @@ def main() -> None:
     for _ in range(args.warmup):
         train_step(step_model, opt, X, y, 1.0, sync_grads=sync)
     barrier()
-    ops.prof_enable(True)
-    ops.prof_collect()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        logits, loss, aux, gnorm = train_step(step_model, opt, X, y, 1.0, sync_grads=sync)
-    barrier()
-    dt = time.perf_counter() - t0
+    prof_steps = args.steps
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is single-process (the data-parallel step runs eagerly)")
+        graphed = GraphedTrainStep(model, opt, X, y, 1.0, warmup=1)
+        graphed(X, y)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            logits, loss, aux, gnorm = graphed(X, y)
+        barrier()
+        dt = time.perf_counter() - t0
+        prof_steps = min(args.steps, 3)
+        ops.prof_enable(True)
+        ops.prof_collect()
+        for _ in range(prof_steps):
+            train_step(step_model, opt, X, y, 1.0)
+        barrier()
+    else:
+        ops.prof_enable(True)
+        ops.prof_collect()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            logits, loss, aux, gnorm = train_step(step_model, opt, X, y, 1.0, sync_grads=sync)
+        barrier()
+        dt = time.perf_counter() - t0
     ops.prof_enable(False)
     prof = ops.prof_collect()
     if world > 1:
@@ -163,8 +185,11 @@ def main() -> None:
                          "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
                          "launches": g["launches"], "avg_launch_ms": round(g["ms"] / max(1, g["launches"]), 4)},
-            "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in prof.items() if v["launches"]},
+            "kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 3) for k, v in prof.items() if v["launches"]},
         }
+        if args.graph:
+            out["graph"] = True
+            out["roofline"]["source"] = f"{prof_steps} eager steps after the timed hipGraph replays"
         if world == 1 and not args.no_cpu_baseline:
             try:
                 avail = len(os.sched_getaffinity(0))

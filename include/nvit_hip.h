@@ -89,11 +89,15 @@ int nvit_shadow_weights(const int64_t* table, int n, int total_items, int dt, vo
  * nvit_adamw_renorm: clip = min(1, max_norm / (sqrt(sum partial) + 1e-6)) when partial != NULL and max_norm > 0;
  *        g *= clip; torch AdamW update (decoupled decay, bias corrections 1 - beta^t passed by the host); rows /
  *        columns of kind 1 / 0 matrices are L2-normalised before the single write-back.  gnorm_out[0] (optional)
- *        receives the pre-clip global gradient norm.  max_slab_rows = largest `rows` among kind-0 entries. */
+ *        receives the pre-clip global gradient norm.  max_slab_rows = largest `rows` among kind-0 entries.
+ *        hyper (optional, 3 floats on the device): when given, the bias corrections are read from hyper[1..2] as
+ *        maintained by nvit_adamw_tick (hyper[0] = step count; one call per optimizer step, before this one), so the
+ *        whole step can be captured in a hipGraph and replayed; the two double arguments are then ignored. */
+int nvit_adamw_tick(float* hyper, double beta1, double beta2, void* stream);
 int nvit_grad_sqnorm(const int64_t* table, int n, int total_chunks, float* partial, int npart, void* stream);
 int nvit_adamw_renorm(const int64_t* table, int n, int total_items, int max_slab_rows, float beta1, float beta2,
                       float eps, double bias_correction1, double bias_correction2, const float* partial, int npart,
-                      float max_norm, float* gnorm_out, void* stream);
+                      float max_norm, float* gnorm_out, const float* hyper, void* stream);
 
 /* ---- GEMMs ------------------------------------------------------------------------
  * nvit_gemm_nt: C[M,N] = A[M,K] * B[N,K]^T  (nn.Linear: model.py:99-101,130,148,155,...)

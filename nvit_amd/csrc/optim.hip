@@ -127,10 +127,15 @@ __device__ __forceinline__ void adam4(f32x4& p, const f32x4& g, f32x4& m, f32x4&
 // 1024 threads = 16 waves, one workgroup per CU (the column slab takes most of the LDS), so the streaming items
 // still have 16 waves x 4 tensors of loads in flight per CU.
 __global__ __launch_bounds__(1024) void adamw_renorm_kernel(const int64_t* table, int n, int total_items,
-                                                            const float* partial, AdamArgs a, float* gnorm_out) {
+                                                            const float* partial, AdamArgs a, float* gnorm_out,
+                                                            const float* hyper) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float red[16];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (hyper) {  // bias corrections of the device-side step counter (nvit_adamw_tick): hipGraph replays stay correct
+    a.inv_bc1 = hyper[1];
+    a.inv_sqrt_bc2 = hyper[2];
+  }
   // global gradient norm -> clip factor (every workgroup sums the same partials in the same order)
   float clip = 1.0f;
   if (partial) {
@@ -261,7 +266,23 @@ __global__ __launch_bounds__(1024) void adamw_renorm_kernel(const int64_t* table
   }
 }
 
+// hyper[0] = step count t (after the increment), hyper[1] = 1/(1-b1^t), hyper[2] = 1/sqrt(1-b2^t)
+__global__ void adamw_tick_kernel(float* hyper, double b1, double b2) {
+  const double t = (double)hyper[0] + 1.0;
+  hyper[0] = (float)t;
+  hyper[1] = (float)(1.0 / (1.0 - pow(b1, t)));
+  hyper[2] = (float)(1.0 / sqrt(1.0 - pow(b2, t)));
+}
+
 }  // namespace
+
+extern "C" int nvit_adamw_tick(float* hyper, double beta1, double beta2, void* stream) {
+  NVIT_REQUIRE(hyper && beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0, "adamw_tick: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(adamw_tick_kernel, dim3(1), dim3(1), 0, s, hyper, beta1, beta2);
+  NVIT_CHECK_LAUNCH("adamw_tick");
+  return NVIT_OK;
+}
 
 extern "C" int nvit_grad_sqnorm(const int64_t* table, int n, int total_chunks, float* partial, int npart,
                                 void* stream) {
@@ -275,18 +296,20 @@ extern "C" int nvit_grad_sqnorm(const int64_t* table, int n, int total_chunks, f
 
 extern "C" int nvit_adamw_renorm(const int64_t* table, int n, int total_items, int max_slab_rows, float beta1,
                                  float beta2, float eps, double bias_correction1, double bias_correction2,
-                                 const float* partial, int npart, float max_norm, float* gnorm_out, void* stream) {
+                                 const float* partial, int npart, float max_norm, float* gnorm_out,
+                                 const float* hyper, void* stream) {
   NVIT_REQUIRE(table && n > 0 && total_items > 0, "adamw_renorm: empty table");
   NVIT_REQUIRE(max_slab_rows >= 0 && max_slab_rows <= 1152,
                "adamw_renorm: column-normalised matrix with %d rows exceeds the LDS slab (1152)", max_slab_rows);
-  NVIT_REQUIRE(bias_correction1 > 0.0 && bias_correction2 > 0.0, "adamw_renorm: bias corrections must be > 0");
+  NVIT_REQUIRE(hyper || (bias_correction1 > 0.0 && bias_correction2 > 0.0),
+               "adamw_renorm: bias corrections must be > 0");
   NVIT_REQUIRE(!partial || (npart > 0 && npart <= 4096), "adamw_renorm: bad npart");
   AdamArgs a;
   a.b1 = beta1;
   a.b2 = beta2;
   a.eps = eps;
-  a.inv_bc1 = (float)(1.0 / bias_correction1);
-  a.inv_sqrt_bc2 = (float)(1.0 / sqrt(bias_correction2));
+  a.inv_bc1 = hyper ? 0.f : (float)(1.0 / bias_correction1);
+  a.inv_sqrt_bc2 = hyper ? 0.f : (float)(1.0 / sqrt(bias_correction2));
   a.max_norm = max_norm;
   a.npart = npart;
   hipStream_t s = (hipStream_t)stream;
@@ -299,7 +322,7 @@ extern "C" int nvit_adamw_renorm(const int64_t* table, int n, int total_items, i
   }
   int grid = total_items < 2048 ? total_items : 2048;
   ProfScope ps(NVIT_KID_RENORM, 0.0, 0.0, s);
-  hipLaunchKernelGGL(adamw_renorm_kernel, dim3(grid), dim3(1024), lds, s, table, n, total_items, partial, a, gnorm_out);
+  hipLaunchKernelGGL(adamw_renorm_kernel, dim3(grid), dim3(1024), lds, s, table, n, total_items, partial, a, gnorm_out, hyper);
   NVIT_CHECK_LAUNCH("adamw_renorm");
   return NVIT_OK;
 }

@@ -39,6 +39,9 @@ class FusedAdamW(torch.optim.AdamW):
         # the torch base class is only the container (param groups, state, state_dict); its kernels never run
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, foreach=False, fused=False)
         self._cache = None
+        self._t = 0          # optimizer steps taken (host mirror of the device counter hyper[0])
+        self._hyper = None   # device float[3]: step, 1/(1-b1^t), 1/sqrt(1-b2^t) - maintained by nvit_adamw_tick
+        self._staging = None  # pinned host image of the device table
 
     # ------------------------------------------------------------------ state
     def _ensure_state(self, p: torch.Tensor) -> Dict:
@@ -108,9 +111,19 @@ class FusedAdamW(torch.optim.AdamW):
                     break
                 if dev is not None:
                     break
+            # Host copy of the table in a persistent pinned buffer, device copy by an async memcpy: legal while a
+            # hipGraph is being captured (the gradients autograd allocates inside the capture have new addresses, so
+            # the table is rebuilt there once; the captured memcpy then re-sends this buffer on every replay, which
+            # is also how a later learning-rate change reaches a captured step).
+            n = len(rows)
+            if self._staging is None or self._staging.shape[0] < n:
+                self._staging = torch.empty((max(n, 64), 10), dtype=torch.int64).pin_memory()
+            self._staging[:n].copy_(torch.tensor(rows, dtype=torch.int64))
+            table = torch.empty((n, 10), dtype=torch.int64, device=dev)
+            table.copy_(self._staging[:n], non_blocking=True)
             self._cache = {
                 "key": key,
-                "table": torch.tensor(rows, dtype=torch.int64).to(dev),
+                "table": table,
                 "n": len(rows), "items": first_item, "chunks": first_chunk, "slab": max_slab_rows,
                 "partial": torch.empty(_NPART, device=dev, dtype=torch.float32),
                 "gnorm": torch.empty(1, device=dev, dtype=torch.float32),
@@ -135,30 +148,78 @@ class FusedAdamW(torch.optim.AdamW):
         c = self._table(dims)
         if c is None:
             return None
-        # per-parameter step counters (host side, as torch's non-capturable AdamW keeps them)
-        t = None
-        for group in self.param_groups:
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                st = self.state[p]
-                st["step"] += 1
-                tp = float(st["step"])
-                if t is None:
-                    t = tp
-                elif tp != t:
-                    raise RuntimeError("FusedAdamW: parameters with different step counts are not supported")
         b1, b2, eps = c["betas_eps"]
         lib = _lib.load()
+        dev = c["table"].device
+        if self._hyper is None:
+            self._t = self._loaded_step()
+            self._hyper = torch.tensor([float(self._t), 0.0, 0.0], dtype=torch.float32).pin_memory().to(
+                dev, non_blocking=True)
+        # the step counter lives on the device (bias corrections are computed there), so a captured step replays
+        # correctly; the host mirror only feeds state_dict()
+        check(lib.nvit_adamw_tick(_p(self._hyper), b1, b2, _s()), "nvit_adamw_tick")
+        self._t += 1
         clip = grad_clip is not None and grad_clip > 0.0
         if clip:
             check(lib.nvit_grad_sqnorm(_p(c["table"]), c["n"], c["chunks"], _p(c["partial"]), _NPART, _s()),
                   "nvit_grad_sqnorm")
-        check(lib.nvit_adamw_renorm(_p(c["table"]), c["n"], c["items"], c["slab"], b1, b2, eps, 1.0 - b1 ** t,
-                                    1.0 - b2 ** t, _p(c["partial"]) if clip else None, _NPART if clip else 0,
-                                    float(grad_clip) if clip else 0.0, _p(c["gnorm"]) if clip else None, _s()),
+        check(lib.nvit_adamw_renorm(_p(c["table"]), c["n"], c["items"], c["slab"], b1, b2, eps, 0.0, 0.0,
+                                    _p(c["partial"]) if clip else None, _NPART if clip else 0,
+                                    float(grad_clip) if clip else 0.0, _p(c["gnorm"]) if clip else None,
+                                    _p(self._hyper), _s()),
               "nvit_adamw_renorm")
         return c["gnorm"] if clip else None
+
+    # ------------------------------------------------------------------ step counter <-> torch's per-parameter state
+    def _loaded_step(self) -> int:
+        """Step count found in the (possibly loaded) per-parameter state; all parameters must agree."""
+        t = None
+        for st in self.state.values():
+            if "step" in st:
+                v = int(float(st["step"]))
+                if t is not None and v != t:
+                    raise RuntimeError("FusedAdamW: parameters with different step counts are not supported")
+                t = v
+        return t or 0
+
+    def rewrite_hyper(self) -> None:
+        """Push the param groups' current lr / weight_decay into the device table in place (same addresses, so a
+        captured step picks them up on its next replay)."""
+        c = self._cache
+        if c is None:
+            return
+        col, i = [], 0
+        for group in self.param_groups:
+            hyper = _f32_bits(group["lr"]) | (_f32_bits(group["weight_decay"]) << 32)
+            if hyper >= 1 << 63:
+                hyper -= 1 << 64
+            for p in group["params"]:
+                if p.grad is not None:
+                    col.append(hyper)
+        if len(col) != c["n"]:
+            raise RuntimeError("FusedAdamW.rewrite_hyper: parameter set changed since the table was built")
+        self._staging[:c["n"], 9].copy_(torch.tensor(col, dtype=torch.int64))
+        c["table"].copy_(self._staging[:c["n"]], non_blocking=True)
+        groups = [g for g in self.param_groups for p in g["params"] if p.grad is not None]
+        c["key"] = tuple((k[0], k[1], k[2], g["lr"], g["weight_decay"]) for k, g in zip(c["key"], groups))
+
+    def note_replay(self, n: int = 1) -> None:
+        """A captured step was replayed n times (the device counter advanced; keep the host mirror in sync)."""
+        self._t += n
+
+    def _sync_state_steps(self) -> None:
+        for st in self.state.values():
+            if "exp_avg" in st:
+                st["step"] = torch.tensor(float(self._t), dtype=torch.float32)
+
+    def state_dict(self):
+        self._sync_state_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._cache = None
+        self._hyper = None   # re-created from the loaded step count on the next step
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -85,3 +85,58 @@ def train_step(model, optimizer, X: torch.Tensor, y: torch.Tensor, grad_clip: fl
         optimizer.zero_grad(set_to_none=True)
         normalize_matrices(model)
     return logits.detach(), loss.detach(), aux, gnorm
+
+
+class GraphedTrainStep:
+    """The whole train step (forward, loss, backward, clip + AdamW + renorm) captured once as a hipGraph and replayed.
+
+    SURVEY.md §8f F2: for C1-sized models the eager step is bound by ~600 kernel launches, not by the GPU.  Needs the
+    FusedAdamW optimizer (its step counter and bias corrections live on the device, so replays stay correct), a
+    model without the Kohonen head (its SOM schedule is host state), a fixed batch shape and a single process
+    (the data-parallel wrapper launches RCCL work from autograd hooks and stays eager).  The learning rate is the one
+    in the optimizer's param groups at capture time; `set_lr` rewrites it on the device between replays.
+    """
+
+    def __init__(self, model, optimizer, X: torch.Tensor, y: torch.Tensor, grad_clip: float = 1.0, warmup: int = 3):
+        m = _unwrap(model)
+        if not isinstance(optimizer, FusedAdamW):
+            raise RuntimeError("GraphedTrainStep needs the FusedAdamW returned by ViT.configure_optimizers")
+        if m.config.use_kohonen:
+            raise RuntimeError("GraphedTrainStep: the Kohonen head keeps host-side step state; run it eagerly")
+        if hasattr(model, "module"):
+            raise RuntimeError("GraphedTrainStep: wrap the bare model (data-parallel steps run eagerly)")
+        if X.device.type != "cuda":
+            raise RuntimeError("GraphedTrainStep: inputs must live on the HIP device")
+        self.model, self.optimizer, self.grad_clip = model, optimizer, grad_clip
+        self.X, self.y = X.clone(), y.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):   # builds every cache (shadow/renorm tables, LDS attributes, workspaces)
+                train_step(model, optimizer, self.X, self.y, grad_clip)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        optimizer.zero_grad(set_to_none=True)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            logits, aux = model(self.X)
+            loss = total_loss(m.config, logits, aux, self.y)
+            loss.backward()
+            gnorm = optimizer.step_fused(model, grad_clip)
+        self.logits, self.loss, self.aux = logits.detach(), loss.detach(), aux
+        self.gnorm = gnorm
+        optimizer.note_replay(-1)   # the capture pass records the step but does not execute it
+
+    def set_lr(self, lr: float) -> None:
+        for group in self.optimizer.param_groups:
+            group["lr"] = lr
+        self.optimizer.rewrite_hyper()
+
+    def __call__(self, X: torch.Tensor, y: torch.Tensor):
+        """One optimizer step on (X, y); returns (logits, loss, aux, grad_norm) as static device tensors that the
+        next call overwrites."""
+        self.X.copy_(X, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        self.graph.replay()
+        self.optimizer.note_replay()
+        return self.logits, self.loss, self.aux, (self.gnorm[0] if self.gnorm is not None else None)
