@@ -265,6 +265,12 @@ int nvit_som_smooth_bwd(const float* nodes, const float* D, const int* cnt, cons
 int nvit_recon_bwd(int dt, const float* raw, const float* img, const float* g, void* draw, int B, int ch, int S, int P,
                    void* stream);
 
+/* Loss side: F.cross_entropy(logits, Y) of train.py:906 with its gradient in the same pass.
+ * rowloss[B] (workspace) = logsumexp(row) - row[label]; loss[0] = mean; dlogits[B,N] = (softmax - onehot) / B
+ * (multiply by the upstream scalar gradient).  Labels outside [0,N) contribute 0 loss (and a plain softmax/B row). */
+int nvit_ce_loss(const float* logits, const int64_t* labels, float* rowloss, float* loss, float* dlogits, int B, int N,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -247,3 +247,60 @@ extern "C" int nvit_recon_loss(const float* raw, const float* img, float* part, 
   NVIT_CHECK_LAUNCH("recon_final");
   return NVIT_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Cross-entropy loss, forward and gradient in one pass (reference train.py:906
+// `F.cross_entropy(logits, Y)`: mean over the batch of logsumexp(row) - row[label]).  One workgroup per sample writes
+// rowloss[b] and dlogits[b,:] = (softmax(row) - onehot(label)) / B; a single-workgroup launch sums the row losses in
+// a fixed order (deterministic).
+namespace {
+
+__global__ __launch_bounds__(256) void ce_rows_kernel(const float* logits, const int64_t* labels, float* rowloss,
+                                                      float* dlogits, int B, int N) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const float* row = logits + (size_t)b * N;
+  float mx = -INFINITY;
+  for (int n = tid; n < N; n += 256) mx = fmaxf(mx, row[n]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) red[wid] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float s = 0.f;
+  for (int n = tid; n < N; n += 256) s += expf(row[n] - mx);
+  s = wave_sum(s);
+  if (lane == 0) red[wid] = s;
+  __syncthreads();
+  s = red[0] + red[1] + red[2] + red[3];
+  const int lab = (int)labels[b];
+  const float lse = mx + logf(s);
+  if (tid == 0) rowloss[b] = (lab >= 0 && lab < N) ? lse - row[lab] : 0.f;
+  const float inv = 1.0f / s, invB = 1.0f / (float)B;
+  float* drow = dlogits + (size_t)b * N;
+  for (int n = tid; n < N; n += 256) drow[n] = (expf(row[n] - mx) * inv - (n == lab ? 1.0f : 0.0f)) * invB;
+}
+
+__global__ __launch_bounds__(256) void ce_mean_kernel(const float* rowloss, float* loss, int B) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float s = 0.f;
+  for (int b = tid; b < B; b += 256) s += rowloss[b];
+  s = wave_sum(s);
+  if (lane == 0) red[wid] = s;
+  __syncthreads();
+  if (tid == 0) loss[0] = (red[0] + red[1] + red[2] + red[3]) / (float)B;
+}
+
+}  // namespace
+
+extern "C" int nvit_ce_loss(const float* logits, const int64_t* labels, float* rowloss, float* loss, float* dlogits,
+                            int B, int N, void* stream) {
+  NVIT_REQUIRE(logits && labels && rowloss && loss && dlogits && B > 0 && N > 0, "ce_loss: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(B), dim3(256), 0, s, logits, labels, rowloss, dlogits, B, N);
+  hipLaunchKernelGGL(ce_mean_kernel, dim3(1), dim3(256), 0, s, rowloss, loss, B);
+  NVIT_CHECK_LAUNCH("ce_loss");
+  return NVIT_OK;
+}

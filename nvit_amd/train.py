@@ -51,11 +51,34 @@ def normalize_matrices(model) -> None:
     ops.renorm_weights(cache[1], cache[2])
 
 
+class CrossEntropyFn(torch.autograd.Function):
+    """F.cross_entropy(logits, y) (reference train.py:906) as one HIP pass that also produces the gradient."""
+
+    @staticmethod
+    def forward(ctx, logits, y):
+        if logits.device.type != "cuda" or logits.dtype != torch.float32 or y.dtype != torch.int64:
+            raise RuntimeError("CrossEntropyFn: fp32 logits and int64 labels on the HIP device (no CPU path)")
+        logits = logits.contiguous()
+        B, N = logits.shape
+        rowloss = torch.empty(B, device=logits.device, dtype=torch.float32)
+        loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+        dlogits = torch.empty_like(logits)
+        ops.check(ops._lib.load().nvit_ce_loss(ops._p(logits), ops._p(y.contiguous()), ops._p(rowloss), ops._p(loss),
+                                               ops._p(dlogits), B, N, ops._s()), "nvit_ce_loss")
+        ctx.save_for_backward(dlogits)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dlogits,) = ctx.saved_tensors
+        return dlogits * g, None
+
+
 def total_loss(config, logits: torch.Tensor, aux, y: torch.Tensor, consistency_weight: float = 0.1,
                smoothness_weight: float = 0.1) -> torch.Tensor:
     """Loss of the reference loop (train.py:906-926): CE, plus the weighted aux losses iff the Kohonen head is on
     (consistency/smoothness weights are settings.yaml `training.*`, the others come from the model config)."""
-    loss = F.cross_entropy(logits, y)
+    loss = CrossEntropyFn.apply(logits, y)
     if config.use_kohonen:
         loss = (loss + consistency_weight * aux["kohonen_consistency"] + smoothness_weight * aux["kohonen_smoothness"]
                 + config.local_quantization_weight * aux["local_quantization"]

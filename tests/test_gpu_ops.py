@@ -436,3 +436,19 @@ def _step_with_dims(opt, dims, grad_clip):
     blk.att_c_proj, blk.mlp_c_proj = W(cols[0]), W(cols[1])
     m.transformer = types.SimpleNamespace(h=[blk])
     return opt.step_fused(m, grad_clip)
+
+
+@pytest.mark.parametrize("B,N", [(8, 10), (128, 1000), (3, 7), (33, 100)])
+def test_ce_loss_fwd_bwd(B, N):
+    """nvit_ce_loss (loss + gradient in one pass) against F.cross_entropy and its autograd on CPU fp32."""
+    from nvit_amd.train import CrossEntropyFn
+    logits = rnd(B, N, seed=5, scale=3.0)
+    y = torch.randint(0, N, (B,), generator=torch.Generator().manual_seed(6))
+    lr = logits.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lr, y)
+    (ref * 1.7).backward()
+    lg = logits.to(dev()).requires_grad_(True)
+    out = CrossEntropyFn.apply(lg, y.to(dev()))
+    (out * 1.7).backward()
+    assert abs(out.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
+    assert (lg.grad.cpu() - lr.grad).abs().max().item() <= 2e-7
