@@ -44,7 +44,9 @@ const char* nvit_last_error(void);
 #define NVIT_KID_SHADOW 6
 #define NVIT_KID_PATCHIFY 7
 #define NVIT_KID_MISC 8
-#define NVIT_KID_COUNT 9
+#define NVIT_KID_GEMM_F32 9 /* exact-f32 MFMA GEMMs (fp32 mode; patch embedding + classifier of the bf16 mode) */
+#define NVIT_KID_GEMM_FUSED 10 /* bf16 NT GEMMs with a fused epilogue: SwiGLU, q/k normalise, SwiGLU backward */
+#define NVIT_KID_COUNT 11
 void nvit_prof_enable(int on);
 /* Synchronises the recorded events and returns, per kernel family, total milliseconds,
  * algorithmic FLOPs, algorithmic bytes and launch count since the last collect. Host arrays

@@ -380,7 +380,7 @@ extern "C" int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int l
   const long long blocks = (long long)cdiv(M, BM) * g.tiles_n;
   NVIT_REQUIRE(blocks < (1ll << 31), "gemm_nt: grid too large");
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_GEMM_NT, 2.0 * M * N * K, 0.0, s);
+  ProfScope ps(dt == NVIT_F32 ? NVIT_KID_GEMM_F32 : NVIT_KID_GEMM_NT, 2.0 * M * N * K, 0.0, s);
   {
     // large problems: persistent kernels (gemm_p.hip), 256x256 tiles when N allows, else 256x128.
     // NVIT_GEMM_NT_IMPL=0 forces the 128x128 kernel, NVIT_GEMM_NT_TILE=128|256 forces a tile width.
@@ -439,7 +439,7 @@ extern "C" int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int l
   g.tiles_k = cdiv(K, BM);
   dim3 grid((unsigned)(cdiv(N, BN) * g.tiles_k), (unsigned)splits);
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_GEMM_TN, 2.0 * Mred * (double)N * K, 0.0, s);
+  ProfScope ps(dt == NVIT_F32 ? NVIT_KID_GEMM_F32 : NVIT_KID_GEMM_TN, 2.0 * Mred * (double)N * K, 0.0, s);
   {
     hipError_t e = hipMemsetAsync(ws + (size_t)splits * N * K, 0, 256, s);
     if (e != hipSuccess) NVIT_FAIL((int)e, "gemm_tn: memset: %s", hipGetErrorString(e));
@@ -503,7 +503,7 @@ extern "C" int nvit_gemm_nt_swiglu(int dt, const void* A, int lda, const void* B
   g.gs = gs;
   g.gscale = gscale;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_GEMM_NT, 2.0 * M * (2.0 * F) * K, 0.0, s);
+  ProfScope ps(NVIT_KID_GEMM_FUSED, 2.0 * M * (2.0 * F) * K, 0.0, s);
   return nvit_gemm_nt_fused_launch(g, 3, s);
 }
 
@@ -534,7 +534,7 @@ extern "C" int nvit_gemm_nt_swiglu_bwd(int dt, const void* A, int lda, const voi
   g.gscale = gscale;
   g.part = gs ? part : nullptr;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_GEMM_NT, 2.0 * M * (double)F * K, 0.0, s);
+  ProfScope ps(NVIT_KID_GEMM_FUSED, 2.0 * M * (double)F * K, 0.0, s);
   return nvit_gemm_nt_fused_launch(g, 5, s);
 }
 
@@ -570,6 +570,6 @@ extern "C" int nvit_gemm_nt_qknorm(int dt, const void* A, int lda, const void* B
   g.Ttok = T;
   g.H = H;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_GEMM_NT, 2.0 * M * (double)(nparts * C) * K, 0.0, s);
+  ProfScope ps(NVIT_KID_GEMM_FUSED, 2.0 * M * (double)(nparts * C) * K, 0.0, s);
   return nvit_gemm_nt_fused_launch(g, 4, s);
 }

@@ -111,16 +111,24 @@ class FusedAdamW(torch.optim.AdamW):
                     break
                 if dev is not None:
                     break
-            # Host copy of the table in a persistent pinned buffer, device copy by an async memcpy: legal while a
-            # hipGraph is being captured (the gradients autograd allocates inside the capture have new addresses, so
-            # the table is rebuilt there once; the captured memcpy then re-sends this buffer on every replay, which
-            # is also how a later learning-rate change reaches a captured step).
             n = len(rows)
-            if self._staging is None or self._staging.shape[0] < n:
-                self._staging = torch.empty((max(n, 64), 10), dtype=torch.int64).pin_memory()
-            self._staging[:n].copy_(torch.tensor(rows, dtype=torch.int64))
+            host = torch.tensor(rows, dtype=torch.int64)
             table = torch.empty((n, 10), dtype=torch.int64, device=dev)
-            table.copy_(self._staging[:n], non_blocking=True)
+            if torch.cuda.is_current_stream_capturing():
+                # Inside a hipGraph capture (the gradients autograd allocates there have new addresses, so the table is
+                # rebuilt once): pinned memory cannot be allocated now, so the image goes through the persistent
+                # staging buffer that GraphedTrainStep reserved; the captured memcpy re-sends that buffer on every
+                # replay, which is also how a later learning-rate change reaches the captured step.
+                if self._staging is None or self._staging.shape[0] < n:
+                    raise RuntimeError("FusedAdamW: call reserve_staging() before capturing a step")
+                self._staging[:n].copy_(host)
+                table.copy_(self._staging[:n], non_blocking=True)
+                staged = True
+            else:
+                # eager: a fresh pinned image per rebuild (the host allocator keeps it alive until the async copy has
+                # run; re-using one buffer would race with copies still queued behind a GPU that runs steps behind)
+                table.copy_(host.pin_memory(), non_blocking=True)
+                staged = False
             self._cache = {
                 "key": key,
                 "table": table,
@@ -128,6 +136,7 @@ class FusedAdamW(torch.optim.AdamW):
                 "partial": torch.empty(_NPART, device=dev, dtype=torch.float32),
                 "gnorm": torch.empty(1, device=dev, dtype=torch.float32),
                 "betas_eps": beta_eps,
+                "staged": staged,
             }
         return self._cache
 
@@ -198,10 +207,21 @@ class FusedAdamW(torch.optim.AdamW):
                     col.append(hyper)
         if len(col) != c["n"]:
             raise RuntimeError("FusedAdamW.rewrite_hyper: parameter set changed since the table was built")
-        self._staging[:c["n"], 9].copy_(torch.tensor(col, dtype=torch.int64))
-        c["table"].copy_(self._staging[:c["n"]], non_blocking=True)
+        hcol = torch.tensor(col, dtype=torch.int64)
+        if c["staged"]:
+            torch.cuda.current_stream().synchronize()   # no replay may be reading the staging buffer while it changes
+            self._staging[:c["n"], 9].copy_(hcol)
+            c["table"].copy_(self._staging[:c["n"]], non_blocking=True)
+        else:
+            c["table"][:, 9].copy_(hcol.pin_memory(), non_blocking=True)
         groups = [g for g in self.param_groups for p in g["params"] if p.grad is not None]
         c["key"] = tuple((k[0], k[1], k[2], g["lr"], g["weight_decay"]) for k, g in zip(c["key"], groups))
+
+    def reserve_staging(self) -> None:
+        """Pinned host image for the parameter table, allocated ahead of a hipGraph capture."""
+        n = sum(len(g["params"]) for g in self.param_groups)
+        if self._staging is None or self._staging.shape[0] < n:
+            self._staging = torch.empty((max(n, 64), 10), dtype=torch.int64).pin_memory()
 
     def note_replay(self, n: int = 1) -> None:
         """A captured step was replayed n times (the device counter advanced; keep the host mirror in sync)."""

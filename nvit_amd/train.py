@@ -140,6 +140,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         optimizer.zero_grad(set_to_none=True)
+        optimizer.reserve_staging()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             logits, aux = model(self.X)

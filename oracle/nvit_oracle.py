@@ -159,8 +159,9 @@ def embed(p: Params, cfg, img: Tensor, lowp: LowP) -> Tuple[Tensor, Tensor, Tens
     C = cfg.n_embd
     A_l = im2col(img, Pl, Pl, 0)
     A_g = im2col(img, Pg, Pl, (Pg - Pl) // 2)
-    loc = linear(A_l, p["local_patch_embed.weight"].reshape(C, -1), p["local_patch_embed.bias"], lowp)
-    glo = linear(A_g, p["global_patch_embed.1.weight"].reshape(C, -1), p["global_patch_embed.1.bias"], lowp)
+    # (the HIP path's bf16 mode keeps the two patch-embedding GEMMs in exact fp32, so the emulation does too)
+    loc = linear(A_l, p["local_patch_embed.weight"].reshape(C, -1), p["local_patch_embed.bias"], None)
+    glo = linear(A_g, p["global_patch_embed.1.weight"].reshape(C, -1), p["global_patch_embed.1.bias"], None)
     return loc + p["local_pos_embed"], glo + p["global_pos_embed"], A_l
 
 
@@ -281,7 +282,9 @@ def forward(p: Params, cfg, img: Tensor, lowp: LowP = None, taps: Optional[dict]
             taps[f"x{i + 1}"] = x
     pooled = x.mean(dim=1)
     ln = layer_norm(pooled, p["mlp_head.0.weight"], p["mlp_head.0.bias"])
-    logits = linear(ln, p["mlp_head.1.weight"], p["mlp_head.1.bias"], lowp)
+    # the classifier GEMM ([B,C]x[C,ncls], negligible work) stays fp32 in the HIP path's bf16 mode, so the bf16-operand
+    # emulation does not round its operands either
+    logits = linear(ln, p["mlp_head.1.weight"], p["mlp_head.1.bias"], None)
     logits = logits * (p["sz"] * (cfg.sz_init_value / cfg.sz_init_scaling))
     rec = torch.tanh(linear(x, p["reconstruction_head.0.weight"], p["reconstruction_head.0.bias"], lowp))
     aux["reconstruction"] = ((rec - A_l) ** 2).mean()
