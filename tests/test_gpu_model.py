@@ -116,7 +116,7 @@ def test_bf16_forward_backward_vs_oracle(name, batch):
     lmax = logits_ref.abs().max().item()
     print(f"[bf16 {name}] max|dlogit| vs fp32 oracle {err:.3e} (|logit|max {lmax:.3f}, rel {err / lmax:.3e}); "
           f"vs bf16-operand oracle {err_emu:.3e}")
-    assert err < 5e-3
+    assert err < 1e-3   # the north-star bf16 bar, against the pure fp32 oracle
     # gradients: cosine similarity per parameter against the fp32 oracle
     worst = 1.0
     for n, q in m.named_parameters():
