@@ -30,6 +30,7 @@ extern "C" {
 #define NVIT_EINVAL 1001
 #define NVIT_F32 0
 #define NVIT_BF16 1
+#define NVIT_BF16X3 2 /* nvit_im2col only: bf16 "hi | lo | hi" split rows, leading dimension 3K (see there) */
 
 int nvit_version(void);
 const char* nvit_last_error(void);
@@ -220,7 +221,9 @@ int nvit_attn_bwd_qknorm(int dt, const void* dout, const void* qh, const void* k
 /* ---- patch embedding / head / reconstruction -------------------------------------------
  * nvit_im2col: A_l [M, ch*Pl*Pl] and A_g [M, ch*Pg*Pg] (type dt, column order (c,ph,pw)) from
  * img fp32 [B,ch,S,S]; global windows are reflect-padded by (Pg-Pl)/2 and strided by Pl
- * (model.py:286-304,407-408). */
+ * (model.py:286-304,407-408).  dt = NVIT_BF16X3 writes rows of 3K bf16 values [hi(x) | x - hi(x) | hi(x)]; a bf16
+ * nvit_gemm_nt over K' = 3K against weights laid out [hi(w) | hi(w) | w - hi(w)] then yields the fp32-accurate
+ * product (hi*hi + lo*hi + hi*lo, ~2^-16 relative) - the bf16 mode's patch embedding. */
 int nvit_im2col(int dt, const float* img, void* A_l, void* A_g, int B, int ch, int S, int Pl, int Pg, void* stream);
 /* mean over tokens + LayerNorm(eps) (model.py:455-456, mlp_head.0): x fp32 [B,T,C] ->
  * pooled [B,C] fp32, ln [B,C] fp32 and ln_lo (type dt, ld = C), stats [B,2] = {mean, rstd}. ws [B, nchunk, C]. */

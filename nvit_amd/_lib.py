@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnvit_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2
 KID_NAMES = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "rowops", "renorm", "shadow", "patchify", "misc", "gemm_f32", "gemm_fused"]
 RENORM_ROWS_PER_ITEM = 16
 RENORM_COLS_PER_ITEM = 32

@@ -9,8 +9,33 @@ __device__ __forceinline__ int reflect(int i, int n) {
   return i >= n ? 2 * (n - 1) - i : i;
 }
 
-// one thread -> 4 consecutive pw of one (token, c, ph); column order (c, ph, pw)
+// Output element writers.  Split3 stores a bf16 "hi | lo | hi" image of each row (leading dimension 3K): against
+// weights laid out "hi | hi | lo" one ordinary bf16 GEMM over 3K then sums hi*hi + lo*hi + hi*lo, i.e. the product
+// of the un-rounded operands to ~2^-16 relative, at three bf16-MFMA passes instead of an exact-f32 MFMA GEMM.
 template <typename T>
+struct ColWriter {
+  static constexpr int MUL = 1;
+  static __device__ __forceinline__ void put(T* row, int K, int k, f32x4 v) { store4<T>(row + k, v); }
+};
+struct Split3 {};
+template <>
+struct ColWriter<Split3> {
+  static constexpr int MUL = 3;
+  static __device__ __forceinline__ void put(bf16* row, int K, int k, f32x4 v) {
+    f32x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = (float)(bf16)v[e];
+      lo[e] = v[e] - hi[e];
+    }
+    store4<bf16>(row + k, hi);
+    store4<bf16>(row + K + k, lo);
+    store4<bf16>(row + 2 * K + k, hi);
+  }
+};
+
+// one thread -> 4 consecutive pw of one (token, c, ph); column order (c, ph, pw)
+template <typename W, typename T>
 __global__ void im2col_kernel(const float* img, T* A_l, T* A_g, int B, int ch, int S, int Pl, int Pg) {
   const int G = S / Pl, Tn = G * G;
   const int Kl = ch * Pl * Pl, Kg = ch * Pg * Pg, pad = (Pg - Pl) / 2;
@@ -23,7 +48,7 @@ __global__ void im2col_kernel(const float* img, T* A_l, T* A_g, int B, int ch, i
       const int b = (int)(m / Tn), t = (int)(m % Tn), ty = t / G, tx = t % G;
       const int c = k / (Pl * Pl), ph = (k / Pl) % Pl, pw = k % Pl;
       const float* src = img + (((size_t)b * ch + c) * S + ty * Pl + ph) * S + tx * Pl + pw;
-      store4<T>(A_l + (size_t)m * Kl + k, *reinterpret_cast<const f32x4*>(src));
+      ColWriter<W>::put(A_l + (size_t)m * Kl * ColWriter<W>::MUL, Kl, k, *reinterpret_cast<const f32x4*>(src));
     } else {
       const long long j = idx - nl;
       const int k = (int)(j % (Kg / 4)) * 4;
@@ -35,7 +60,7 @@ __global__ void im2col_kernel(const float* img, T* A_l, T* A_g, int B, int ch, i
       f32x4 v;
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] = row[reflect(tx * Pl - pad + pw + e, S)];
-      store4<T>(A_g + (size_t)m * Kg + k, v);
+      ColWriter<W>::put(A_g + (size_t)m * Kg * ColWriter<W>::MUL, Kg, k, v);
     }
   }
 }
@@ -195,12 +220,15 @@ extern "C" int nvit_im2col(int dt, const float* img, void* A_l, void* A_g, int B
   const long long n = (long long)B * G * G * ((ch * Pl * Pl + ch * Pg * Pg) / 4);
   int blocks = cdiv(n, 256);
   if (blocks > 8192) blocks = 8192;
-  const double es = dt == NVIT_F32 ? 4.0 : 2.0;
+  NVIT_REQUIRE(dt == NVIT_F32 || dt == NVIT_BF16 || dt == NVIT_BF16X3, "im2col: bad dt %d", dt);
+  const double es = dt == NVIT_F32 ? 4.0 : (dt == NVIT_BF16X3 ? 6.0 : 2.0);
   ProfScope ps(NVIT_KID_PATCHIFY, 0.0, (double)B * ch * S * S * 4.0 + (double)n * 4.0 * es, s);
   if (dt == NVIT_F32)
-    hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, s, img, (float*)A_l, (float*)A_g, B, ch, S, Pl, Pg);
+    hipLaunchKernelGGL((im2col_kernel<float, float>), dim3(blocks), dim3(256), 0, s, img, (float*)A_l, (float*)A_g, B, ch, S, Pl, Pg);
+  else if (dt == NVIT_BF16X3)
+    hipLaunchKernelGGL((im2col_kernel<Split3, bf16>), dim3(blocks), dim3(256), 0, s, img, (bf16*)A_l, (bf16*)A_g, B, ch, S, Pl, Pg);
   else
-    hipLaunchKernelGGL(im2col_kernel<bf16>, dim3(blocks), dim3(256), 0, s, img, (bf16*)A_l, (bf16*)A_g, B, ch, S, Pl, Pg);
+    hipLaunchKernelGGL((im2col_kernel<bf16, bf16>), dim3(blocks), dim3(256), 0, s, img, (bf16*)A_l, (bf16*)A_g, B, ch, S, Pl, Pg);
   NVIT_CHECK_LAUNCH("im2col");
   return NVIT_OK;
 }

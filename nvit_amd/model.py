@@ -27,7 +27,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import BF16, F32
+from ._lib import BF16, BF16X3, F32
 from .config import ViTConfig
 from .kohonen import CosConsistencyFn, HuberFn, KohonenMap, MapSmoothnessFn
 
@@ -445,6 +445,13 @@ class _CrossFn(torch.autograd.Function):
                 g_bproj, g_bout)
 
 
+def _split3_weight(w: torch.Tensor) -> torch.Tensor:
+    """[N,K] fp32 -> [N,3K] bf16 image [hi | hi | lo] (partner of the im2col [hi | lo | hi] rows)."""
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
+    return torch.cat((hi, hi, lo), dim=1)
+
+
 class _EmbedFn(torch.autograd.Function):
     """Dual patch embedding + position embeddings (reference model.py:407-415) as im2col GEMMs."""
 
@@ -457,39 +464,40 @@ class _EmbedFn(torch.autograd.Function):
         T = rt.model.n_tokens
         M = B * T
         Kl, Kg = cfg.channels * Pl * Pl, cfg.channels * Pg * Pg
-        # Precision policy of the bf16 mode: the two patch-embedding GEMMs run as exact-f32 MFMA on the fp32 masters.
-        # They are 0.55 % of the step's FLOPs but their output IS the residual stream, so a bf16-operand rounding here
-        # (1.6e-3 relative) reaches the logits undamped, while every later update is scaled by the LERP rate (~0.05):
-        # max |dlogit| vs the fp32 oracle drops 1.2e-3 -> 1.5e-4 (micro), 1.4e-3 -> 5.1e-4 (mini), 2.6e-3 -> 9.4e-4
-        # (tiny).  The weight gradients stay bf16-operand (im2col is recomputed in backward).
-        A_l, A_g = ops.im2col(F32, img, Pl, Pg)
-        w_l = wl.reshape(C, -1) if rt.dt != F32 else rt.sh["pe_l"]
-        w_g = wg.reshape(C, -1) if rt.dt != F32 else rt.sh["pe_g"]
-        loc = ops.gemm_nt(A_l, w_l, M, C, Kl, bias=bl, rowadd=posl.reshape(T, C), rowadd_period=T)
-        glo = ops.gemm_nt(A_g, w_g, M, C, Kg, bias=bg, rowadd=posg.reshape(T, C), rowadd_period=T)
-        ctx.rt = rt
-        ctx.dims = (B, T, C, M, Kl, Kg, Pl, Pg)
-        ctx.shapes = (wl.shape, wg.shape, posl.shape)
+        # Precision policy of the bf16 mode: the two patch-embedding GEMMs are computed to fp32 accuracy.  They are
+        # 0.55 % of the step's FLOPs but their output IS the residual stream, so a bf16-operand rounding here (1.6e-3
+        # relative) reaches the logits undamped, while every later update is scaled by the LERP rate (~0.05): max
+        # |dlogit| vs the fp32 oracle drops 1.2e-3 -> 1.5e-4 (micro), 1.4e-3 -> 5.1e-4 (mini), 2.6e-3 -> 9.4e-4 (tiny).
+        # Done on the bf16 MFMA path by operand splitting: x = hi + lo, w = hi + lo (bf16 each); im2col writes rows
+        # [hi|lo|hi], the weight image is [hi|hi|lo], and one bf16 GEMM over K' = 3K sums hi*hi + lo*hi + hi*lo
+        # (missing lo*lo ~ 2^-16 relative) - three bf16 passes instead of an 8x slower exact-f32 MFMA GEMM.
         if rt.dt == F32:
-            ctx.save_for_backward(A_l, A_g)
+            A_l, A_g = ops.im2col(F32, img, Pl, Pg)
+            loc = ops.gemm_nt(A_l, rt.sh["pe_l"], M, C, Kl, bias=bl, rowadd=posl.reshape(T, C), rowadd_period=T)
+            glo = ops.gemm_nt(A_g, rt.sh["pe_g"], M, C, Kg, bias=bg, rowadd=posg.reshape(T, C), rowadd_period=T)
         else:
-            ctx.save_for_backward(img)
+            A_l, A_g = ops.im2col(BF16X3, img, Pl, Pg)
+            loc = ops.gemm_nt(A_l, _split3_weight(wl.reshape(C, -1)), M, C, 3 * Kl, bias=bl,
+                              rowadd=posl.reshape(T, C), rowadd_period=T)
+            glo = ops.gemm_nt(A_g, _split3_weight(wg.reshape(C, -1)), M, C, 3 * Kg, bias=bg,
+                              rowadd=posg.reshape(T, C), rowadd_period=T)
+        ctx.rt = rt
+        ctx.dims = (B, T, C, M, Kl, Kg)
+        ctx.shapes = (wl.shape, wg.shape, posl.shape)
+        ctx.save_for_backward(A_l, A_g)
         return loc, glo
 
     @staticmethod
     def backward(ctx, dloc, dglo):
+        A_l, A_g = ctx.saved_tensors   # bf16 mode: the leading K columns of the split image are the bf16 operand
         rt = ctx.rt
-        B, T, C, M, Kl, Kg, Pl, Pg = ctx.dims
-        if rt.dt == F32:
-            A_l, A_g = ctx.saved_tensors
-        else:
-            A_l, A_g = ops.im2col(rt.dt, ctx.saved_tensors[0], Pl, Pg)
+        B, T, C, M, Kl, Kg = ctx.dims
         dev = A_l.device
         out = []
         for dy, A, K in ((dloc, A_l, Kl), (dglo, A_g, Kg)):
             dy = dy.contiguous()
             dy_lo = dy if rt.dt == F32 else ops.cast(dy, rt.dt)
-            gw = ops.gemm_tn(dy_lo, A, torch.empty((C, K), device=dev, dtype=torch.float32), M, C, K)
+            gw = ops.gemm_tn(dy_lo, A[:, :K], torch.empty((C, K), device=dev, dtype=torch.float32), M, C, K)
             dpos = torch.empty((T, C), device=dev, dtype=torch.float32)
             ops.colsum(dy, M, C, dpos, False, period=T)
             db = torch.empty((C,), device=dev, dtype=torch.float32)

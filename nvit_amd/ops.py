@@ -350,10 +350,13 @@ def attn_bwd_qknorm(dout: Tensor, qh: Tensor, kh: Tensor, vh: Tensor, o: Tensor,
 
 # ----------------------------------------------------------------------------- embed / head
 def im2col(dt: int, img: Tensor, Pl: int, Pg: int):
+    """dt = _lib.BF16X3: rows are bf16 [hi | lo | hi] images of width 3K (see nvit_im2col)."""
     B, ch, S, _ = img.shape
     T = (S // Pl) ** 2
-    A_l = torch.empty((B * T, ch * Pl * Pl), device=img.device, dtype=tdtype(dt))
-    A_g = torch.empty((B * T, ch * Pg * Pg), device=img.device, dtype=tdtype(dt))
+    mul = 3 if dt == _lib.BF16X3 else 1
+    td = torch.bfloat16 if dt == _lib.BF16X3 else tdtype(dt)
+    A_l = torch.empty((B * T, mul * ch * Pl * Pl), device=img.device, dtype=td)
+    A_g = torch.empty((B * T, mul * ch * Pg * Pg), device=img.device, dtype=td)
     check(_lib.load().nvit_im2col(dt, _p(img), _p(A_l), _p(A_g), B, ch, S, Pl, Pg, _s()), "nvit_im2col")
     return A_l, A_g
 
