@@ -191,6 +191,22 @@ def main() -> None:
                          "family_achieved_incl_fused_epilogues": round(fam, 1)},
             "kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 3) for k, v in prof.items() if v["launches"]},
         }
+        # HBM-bound kernels of the path: algorithmic bytes (as declared at each launch) / HIP-event time, vs 8 TB/s
+        n_upd = opt._cache["n_elems"] if getattr(opt, "_cache", None) else sum(p.numel() for p in model.parameters())
+        hbm = {}
+        for fam, label in (("rowops", "row kernels (LERP/norm_skip fwd+bwd, reductions)"), ("patchify", "im2col"),
+                           ("shadow", "bf16 operand copies of the weights")):
+            f = prof.get(fam)
+            if f and f["ms"] > 0 and f["bytes"] > 0:
+                hbm[fam] = {"what": label, "GB/s": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1),
+                            "frac_of_8TB/s": round(f["bytes"] / (f["ms"] * 1e-3) / 8e12, 3)}
+        f = prof.get("renorm")
+        if f and f["ms"] > 0:
+            by = 32.0 * n_upd * prof_steps   # p,g,m,v read + p,m,v written + g read again for the global norm
+            hbm["optimizer+renorm"] = {"what": "clip + AdamW + normalize_matrices, 32 B/parameter",
+                                       "GB/s": round(by / (f["ms"] * 1e-3) / 1e9, 1),
+                                       "frac_of_8TB/s": round(by / (f["ms"] * 1e-3) / 8e12, 3)}
+        out["hbm_kernels"] = hbm
         if args.graph:
             out["graph"] = True
             out["roofline"]["source"] = f"{prof_steps} eager steps after the timed hipGraph replays"

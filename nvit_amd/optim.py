@@ -137,6 +137,7 @@ class FusedAdamW(torch.optim.AdamW):
                 "gnorm": torch.empty(1, device=dev, dtype=torch.float32),
                 "betas_eps": beta_eps,
                 "staged": staged,
+                "n_elems": sum(r[4] * r[5] for r in rows),
             }
         return self._cache
 

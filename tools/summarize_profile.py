@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--trace")
     ap.add_argument("--fetch")
     ap.add_argument("--write")
+    ap.add_argument("--mfma", help="PMC pass with SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE")
     ap.add_argument("--cmd", default="")
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
@@ -88,6 +89,24 @@ def main():
             for r in rows[:40]:
                 cw.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                              r["MinNs"], r["MaxNs"]])
+    if a.mfma:
+        # MFMA pipe utilisation per kernel: busy cycles summed over the 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs * 1024)
+        busy = collections.defaultdict(float)
+        act = collections.defaultdict(float)
+        n = collections.Counter()
+        for name, v in counter_rows(a.mfma, "SQ_VALU_MFMA_BUSY_CYCLES"):
+            busy[short(name)] += v
+        for name, v in counter_rows(a.mfma, "GRBM_GUI_ACTIVE"):
+            act[short(name)] += v
+            n[short(name)] += 1
+        with open(os.path.join(out, f"{a.tag}_mfma_util.csv"), "w") as w:
+            w.write(f"# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- {a.cmd}; "
+                    "util = MFMA busy cycles / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)\n")
+            cw = csv.writer(w)
+            cw.writerow(["Kernel", "Launches", "GRBM_GUI_ACTIVE_total", "MFMA_busy_fraction"])
+            for k in sorted(act, key=lambda k: -act[k]):
+                if busy[k] > 0:
+                    cw.writerow([k, n[k], int(act[k]), round(busy[k] / (act[k] / 8 * 1024), 4)])
     pm = {}
     for kind, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
         if not d:
