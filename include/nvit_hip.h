@@ -135,7 +135,8 @@ int nvit_gemm_nt_qknorm(int dt, const void* A, int lda, const void* B, int ldb, 
 
 /* nvit_gemm_tn: weight gradient  G[N,K] (+)= sum_m A[m,N-col] * B[m,K-col]  over Mred rows.
  * A [Mred, N] (lda), B [Mred, K] (ldb) of type dt.  Split over `splits` row chunks into the
- * fp32 workspace ws [splits, N, K] (ws_bytes >= splits*N*K*4 + 256), then reduced in fixed order
+ * fp32 workspace ws [splits, N, K] (ws_bytes >= splits*N*K*4 + 256; the tail is no longer used - zero padding
+ * comes from a device array owned by the library), then reduced in fixed order
  * (deterministic) into G (fp32, ld = ldg): G[perm(n)] = (accumulate ? G : 0) + sum.
  * perm as in nvit_shadow_weights (maps shadow row n to master row). */
 int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int ldb, float* G, int ldg, int Mred, int N,

@@ -408,6 +408,22 @@ extern "C" int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int l
   return NVIT_OK;
 }
 
+// Tail rows / columns of the TN kernels are fetched from a block of zeros.  It is a static device array owned by the
+// library (zero-initialised at module load, never written), not a memset of caller memory per call: a memset node
+// inside a captured hipGraph did not reliably re-zero the block on replay, and 55 tiny memsets per step were 0.26 ms.
+__device__ __attribute__((aligned(256))) float nvit_tn_zero_block[64];
+static const float* tn_zero_block() {
+  static const float* cache[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!cache[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(nvit_tn_zero_block)) != hipSuccess) return nullptr;
+    cache[dev] = (const float*)p;
+  }
+  return cache[dev];
+}
+
 extern "C" int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int ldb, float* G, int ldg, int Mred,
                             int N, int K, int splits, float* ws, int64_t ws_bytes, int perm, int accumulate,
                             void* stream) {
@@ -427,7 +443,8 @@ extern "C" int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int l
   g.A = (const char*)A;
   g.B = (const char*)B;
   g.ws = ws;
-  g.zeros = ws + (size_t)splits * N * K;
+  g.zeros = tn_zero_block();
+  if (!g.zeros) NVIT_FAIL(NVIT_EINVAL, "gemm_tn: cannot resolve the device zero block");
   g.Mred = Mred;
   g.N = N;
   g.K = K;
@@ -440,10 +457,6 @@ extern "C" int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int l
   dim3 grid((unsigned)(cdiv(N, BN) * g.tiles_k), (unsigned)splits);
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(dt == NVIT_F32 ? NVIT_KID_GEMM_F32 : NVIT_KID_GEMM_TN, 2.0 * Mred * (double)N * K, 0.0, s);
-  {
-    hipError_t e = hipMemsetAsync(ws + (size_t)splits * N * K, 0, 256, s);
-    if (e != hipSuccess) NVIT_FAIL((int)e, "gemm_tn: memset: %s", hipGetErrorString(e));
-  }
   bool done = false;
   {
     // big 256-aligned weight shapes: persistent 256x256 kernel (gemm_tn_p.hip); NVIT_GEMM_TN_IMPL=0 disables
@@ -453,7 +466,7 @@ extern "C" int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int l
       impl = e ? atoi(e) : 1;
     }
     if (impl == 1 && Mred >= 4096) {
-      const int rc = nvit_gemm_tn_persistent_launch(dt, A, lda, B, ldb, ws, ws + (size_t)splits * N * K, Mred, N, K,
+      const int rc = nvit_gemm_tn_persistent_launch(dt, A, lda, B, ldb, ws, g.zeros, Mred, N, K,
                                                     splits, s);
       if (rc > 0) return rc;
       done = rc == NVIT_OK;

@@ -107,7 +107,9 @@ def train_step(model, optimizer, X: torch.Tensor, y: torch.Tensor, grad_clip: fl
         optimizer.step()
         optimizer.zero_grad(set_to_none=True)
         normalize_matrices(model)
-    return logits.detach(), loss.detach(), aux, gnorm
+    # detached: a live reference to the step's autograd graph would also pin its AccumulateGrad nodes (and the stream
+    # they were created on), which breaks a later hipGraph capture of the step
+    return logits.detach(), loss.detach(), {k: v.detach() for k, v in aux.items()}, gnorm
 
 
 class GraphedTrainStep:
@@ -132,8 +134,8 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep: inputs must live on the HIP device")
         self.model, self.optimizer, self.grad_clip = model, optimizer, grad_clip
         self.X, self.y = X.clone(), y.clone()
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
+        side = torch.cuda.Stream()   # warm-up and capture share one stream: autograd's gradient accumulators are
+        side.wait_stream(torch.cuda.current_stream())   # bound to the stream they are first used on
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):   # builds every cache (shadow/renorm tables, LDS attributes, workspaces)
                 train_step(model, optimizer, self.X, self.y, grad_clip)
@@ -142,12 +144,13 @@ class GraphedTrainStep:
         optimizer.zero_grad(set_to_none=True)
         optimizer.reserve_staging()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=side):
             logits, aux = model(self.X)
             loss = total_loss(m.config, logits, aux, self.y)
             loss.backward()
             gnorm = optimizer.step_fused(model, grad_clip)
-        self.logits, self.loss, self.aux = logits.detach(), loss.detach(), aux
+        self.logits, self.loss = logits.detach(), loss.detach()
+        self.aux = {k: v.detach() for k, v in aux.items()}
         self.gnorm = gnorm
         optimizer.note_replay(-1)   # the capture pass records the step but does not execute it
 
