@@ -376,3 +376,21 @@ def test_no_uninitialised_reads_under_nan_poison(name, batch):
     assert got[0] == ref[0] and got[1] == ref[1] and got[3] == ref[3] and got[4] == ref[4], (got, ref)
     for n, p in m.named_parameters():
         assert torch.isfinite(p).all(), n
+
+
+def test_kohonen_step_under_nan_poison():
+    """Same check for the Kohonen-head step (eager only: its SOM schedule is host state)."""
+    from nvit_amd.train import train_step
+    cfg = named_config("mini_k")
+    X, y = synthetic_batch(cfg, 4)
+    X, y = X.cuda(), y.cuda()
+    clean = build(cfg, "bf16", True)
+    oc = clean.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")
+    ref = [train_step(clean, oc, X, y)[1].item() for _ in range(3)]
+    m = build(cfg, "bf16", True)
+    o = m.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")
+    got = []
+    for _ in range(3):
+        _poison_free_memory()
+        got.append(train_step(m, o, X, y)[1].item())
+    assert got == ref, (got, ref)
