@@ -394,3 +394,37 @@ def test_kohonen_step_under_nan_poison():
         _poison_free_memory()
         got.append(train_step(m, o, X, y)[1].item())
     assert got == ref, (got, ref)
+
+
+def test_base_config_full_size_vs_cpu_oracle():
+    """BASELINE config C2 at full model size against the CPU oracle itself (B=2: a forward+backward of the fp32 oracle
+    takes a few seconds on the box's host cores): fp32 mode within the 1e-5 logits bar and 1e-3 on gradient norms; the
+    bf16 mode's distance to the same fp32 oracle is printed and bounded."""
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    cfg = named_config("base")
+    X, y = synthetic_batch(cfg, 2)
+    p, logits_ref, loss_ref, _ = oracle_run(cfg, X, y, True)
+    m = build(cfg, "fp32", True).train()
+    logits, aux = m(X.cuda())
+    loss = torch.nn.functional.cross_entropy(logits, y.cuda())
+    loss.backward()
+    err = (logits.detach().cpu() - logits_ref).abs().max().item()
+    print(f"[base vs oracle] fp32 mode max|dlogit| {err:.3e} (|logit|max {logits_ref.abs().max().item():.3f}), "
+          f"loss {loss.item():.6f} vs {loss_ref:.6f}")
+    assert err < 1e-5
+    worst = 0.0
+    for n, q in m.named_parameters():
+        if q.grad is None or p[n].grad is None:
+            continue
+        a, b = q.grad.cpu().double().norm().item(), p[n].grad.double().norm().item()
+        if b > 1e-9:
+            worst = max(worst, abs(a / b - 1))
+    print(f"   worst relative gradient-norm error {worst:.3e}")
+    assert worst < 1e-3
+    m.zero_grad(set_to_none=True)
+    m.set_precision("bf16")
+    with torch.no_grad():
+        lb, _ = m(X.cuda())
+    eb = (lb.cpu() - logits_ref).abs().max().item()
+    print(f"   bf16 mode max|dlogit| vs the fp32 oracle {eb:.3e}")
+    assert eb < 5e-3
