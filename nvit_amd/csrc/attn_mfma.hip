@@ -350,8 +350,12 @@ template <bool FUSE>
 __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
                                                                 const bf16* __restrict__ kh, const bf16* __restrict__ vh,
                                                                 const float* __restrict__ lse,
-                                                                const float* __restrict__ delta, float scale,
-                                                                bf16* __restrict__ dqh, int H, int Tq, int Tk, QkFuse fu) {
+                                                                const bf16* __restrict__ og, float* __restrict__ delta,
+                                                                float scale, bf16* __restrict__ dqh, int H, int Tq,
+                                                                int Tk, QkFuse fu) {
+  // og != NULL: this kernel also produces delta[bh][q] = <dO_q, O_q> (the softmax-backward row term) from the attention
+  // output `og` (token-major like dout) and stores it for the dk/dv kernel, which runs after it; og == NULL: delta
+  // is an input.
   __shared__ __attribute__((aligned(16))) char lds[3][2][TILE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -367,14 +371,29 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
   float lse2[2], dl[2];
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
-    int q = q0 + 16 * f + l15;
-    q = q < Tq ? q : Tq - 1;
+    const int qu = q0 + 16 * f + l15;
+    const int q = qu < Tq ? qu : Tq - 1;
     lse2[f] = lse[(size_t)bh * Tq + q] * LOG2E;
-    dl[f] = delta[(size_t)bh * Tq + q];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       qf[f][ks] = *reinterpret_cast<const uint4*>(qh + ((size_t)bh * Tq + q) * D + ks * 32 + lg * 8);
       gf[f][ks] = *reinterpret_cast<const uint4*>(dout + ((size_t)b * Tq + q) * (H * D) + h * D + ks * 32 + lg * 8);
+    }
+    if (og) {
+      float part = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const uint4 of = *reinterpret_cast<const uint4*>(og + ((size_t)b * Tq + q) * (H * D) + h * D + ks * 32 + lg * 8);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, gf[f][ks]), c = __builtin_bit_cast(bf16x8, of);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += (float)a[e] * (float)c[e];
+      }
+      part += __shfl_xor(part, 16, 64);   // the row's 64 columns live on the 4 lanes l15 + 16*lg
+      part += __shfl_xor(part, 32, 64);
+      dl[f] = part;
+      if (lg == 0 && qu < Tq) delta[(size_t)bh * Tq + qu] = part;
+    } else {
+      dl[f] = delta[(size_t)bh * Tq + q];
     }
   }
   f32x4 dq[4][2];
@@ -636,14 +655,14 @@ int nvit_attn_fwd_mfma(const void* qh, const void* kh, const void* vh, float sca
   return NVIT_OK;
 }
 
-int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const void* vh, const float* lse,
-                       const float* delta, float scale, void* dqh, void* dkh, void* dvh, int B, int H, int Tq, int Tk,
+int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const void* vh, const void* o, const float* lse,
+                       float* delta, float scale, void* dqh, void* dkh, void* dvh, int B, int H, int Tq, int Tk,
                        int d, hipStream_t s) {
   NVIT_REQUIRE(d == 64, "attn_bwd: the MFMA kernel supports head dim 64 only (got %d)", d);
   dim3 gq((unsigned)(cdiv(Tq, 128) * B * H)), gk((unsigned)(cdiv(Tk, 128) * B * H));
   QkFuse none{};
   hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, gq, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
-                     (const bf16*)kh, (const bf16*)vh, lse, delta, scale, (bf16*)dqh, H, Tq, Tk, none);
+                     (const bf16*)kh, (const bf16*)vh, lse, (const bf16*)o, delta, scale, (bf16*)dqh, H, Tq, Tk, none);
   NVIT_CHECK_LAUNCH("attn_bwd_dq_mfma");
   hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
                      (const bf16*)kh, (const bf16*)vh, lse, delta, scale, (bf16*)dkh, (bf16*)dvh, H, Tq, Tk, none);
@@ -653,8 +672,8 @@ int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const v
 
 // attention backward with the q/k-normalise backward fused into the epilogues: writes token-major dq/dk/dv
 // (row stride ld) and the partial sums part_q [B*ceil(Tq/128), C], part_k [B*ceil(Tk/128), C].
-int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, const void* vh, const float* lse,
-                             const float* delta, float scale, const float* rq, const float* rk, const float* sqk,
+int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, const void* vh, const void* o,
+                             const float* lse, float* delta, float scale, const float* rq, const float* rk, const float* sqk,
                              float c_q, void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q, float* part_k, int B,
                              int H, int Tq, int Tk, int d, hipStream_t s) {
   NVIT_REQUIRE(d == 64, "attn_bwd: the MFMA kernel supports head dim 64 only (got %d)", d);
@@ -663,7 +682,7 @@ int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, c
   QkFuse fq{rq, sqk, c_q, (bf16*)dq, nullptr, ldq, part_q};
   QkFuse fk{rk, sqk, c_q, (bf16*)dk, (bf16*)dv, ldkv, part_k};
   hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, gq, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
-                     (const bf16*)kh, (const bf16*)vh, lse, delta, scale, (bf16*)nullptr, H, Tq, Tk, fq);
+                     (const bf16*)kh, (const bf16*)vh, lse, (const bf16*)o, delta, scale, (bf16*)nullptr, H, Tq, Tk, fq);
   NVIT_CHECK_LAUNCH("attn_bwd_dq_mfma_fused");
   hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
                      (const bf16*)kh, (const bf16*)vh, lse, delta, scale, (bf16*)nullptr, (bf16*)nullptr, H, Tq, Tk,

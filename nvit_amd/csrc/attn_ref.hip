@@ -193,12 +193,12 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_ref(const T* dout, const T* q
 
 int nvit_attn_fwd_mfma(const void* qh, const void* kh, const void* vh, float scale, void* o, float* lse, int B, int H,
                        int Tq, int Tk, int d, hipStream_t s);
-int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const void* vh, const float* lse,
-                       const float* delta, float scale, void* dqh, void* dkh, void* dvh, int B, int H, int Tq, int Tk,
+int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const void* vh, const void* o, const float* lse,
+                       float* delta, float scale, void* dqh, void* dkh, void* dvh, int B, int H, int Tq, int Tk,
                        int d, hipStream_t s);
 
-int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, const void* vh, const float* lse,
-                             const float* delta, float scale, const float* rq, const float* rk, const float* sqk,
+int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, const void* vh, const void* o,
+                             const float* lse, float* delta, float scale, const float* rq, const float* rk, const float* sqk,
                              float c_q, void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q, float* part_k, int B,
                              int H, int Tq, int Tk, int d, hipStream_t s);
 
@@ -229,6 +229,11 @@ extern "C" int nvit_attn_bwd(int dt, int impl, const void* dout, const void* qh,
   NVIT_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "attn_bwd: empty problem");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(NVIT_KID_ATTN_BWD, 10.0 * B * H * (double)Tq * Tk * d, 0.0, s);
+  if (impl == 1) {
+    // the MFMA dq kernel computes delta = rowsum(dO * O) itself and leaves it in `delta` for the dk/dv kernel
+    NVIT_REQUIRE(dt == NVIT_BF16, "attn_bwd: MFMA kernel needs bf16");
+    return nvit_attn_bwd_mfma(dout, qh, kh, vh, o, lse, delta, scale, dqh, dkh, dvh, B, H, Tq, Tk, d, s);
+  }
   const long long total = (long long)B * Tq * ((H * d) / 8);
   if (dt == NVIT_F32)
     hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const float*)dout,
@@ -237,10 +242,6 @@ extern "C" int nvit_attn_bwd(int dt, int impl, const void* dout, const void* qh,
     hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const bf16*)dout,
                        (const bf16*)o, delta, B, H, Tq, d);
   NVIT_CHECK_LAUNCH("attn_delta");
-  if (impl == 1) {
-    NVIT_REQUIRE(dt == NVIT_BF16, "attn_bwd: MFMA kernel needs bf16");
-    return nvit_attn_bwd_mfma(dout, qh, kh, vh, lse, delta, scale, dqh, dkh, dvh, B, H, Tq, Tk, d, s);
-  }
   dim3 gq(cdiv(Tq, 64), B * H), gk(cdiv(Tk, 64), B * H);
 #define L(T, D)                                                                                                       \
   do {                                                                                                                \
@@ -265,10 +266,6 @@ extern "C" int nvit_attn_bwd_qknorm(int dt, const void* dout, const void* qh, co
   NVIT_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "attn_bwd_qknorm: empty problem");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(NVIT_KID_ATTN_BWD, 10.0 * B * H * (double)Tq * Tk * d, 0.0, s);
-  const long long total = (long long)B * Tq * ((H * d) / 8);
-  hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3(cdiv(total, 256)), dim3(256), 0, s, (const bf16*)dout,
-                     (const bf16*)o, delta, B, H, Tq, d);
-  NVIT_CHECK_LAUNCH("attn_delta");
-  return nvit_attn_bwd_mfma_fused(dout, qh, kh, vh, lse, delta, scale, rq, rk, sqk, c_q, dq, ldq, dk, dv, ldkv, part_q,
+  return nvit_attn_bwd_mfma_fused(dout, qh, kh, vh, o, lse, delta, scale, rq, rk, sqk, c_q, dq, ldq, dk, dv, ldkv, part_q,
                                   part_k, B, H, Tq, Tk, d, s);
 }
