@@ -124,6 +124,9 @@ int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int ldb, void* C
  *   uv[M,2F] (interleaved, as written by nvit_gemm_nt_swiglu) it writes duv[M,2F] (same layout) and, when gs != NULL
  *   (suv, natural order [u(F)|v(F)]), part[2*ceil(M/256), 2F] = per-128-row partial sums of d(suv) (natural order;
  *   reduce with nvit_colsum_reduce).  Replaces nvit_gemm_nt + nvit_swiglu_bwd.  Requires F % 256 == 0. */
+/* Tile scheduling of the persistent NT GEMM kernels: 0 = static round-robin (default, or NVIT_GEMM_SCHED=static),
+ * 1 = dynamic per-XCD ticket counters (NVIT_GEMM_SCHED=dynamic): robust when other kernels (RCCL) hold some CUs. */
+int nvit_set_gemm_sched(int dynamic);
 int nvit_gemm_nt_fusable(int dt, int M, int N, int K);
 int nvit_gemm_nt_swiglu_bwd(int dt, const void* A, int lda, const void* B, int ldb, const void* uv, void* duv,
                             float* part, int M, int F, int K, const float* gs, float gscale, void* stream);

@@ -37,8 +37,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // EPI: 0 = generic direct epilogue, 1 = LDS-staged bf16 output, 2 = LDS-staged fp32 output,
 //      3 = fused SwiGLU (bf16), 4 = fused q/k-normalise + head split (bf16), 5 = fused SwiGLU backward (bf16)
-template <typename T, int FM, int EPI>
-__global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int tiles_m, int ntiles) {
+// DYN: tiles are handed out at run time instead of statically.  Each XCD owns a contiguous eighth of the (grouped)
+// tile order and a ticket counter; a workgroup's first tile is static, every further one is `Gx + ticket` inside its
+// XCD's range.  The ticket for the tile after next is drawn (one atomic by thread 0) while the current tile is being
+// multiplied and published through LDS one stage later, so the scheduler costs no stall.  What it buys: when other
+// kernels hold some CUs (the RCCL all-reduce of the data-parallel step), workgroups that start late simply take fewer
+// tiles instead of delaying the whole launch by their start offset.  The last workgroup out resets the counters, so
+// a launch leaves them at zero (hipGraph-replay safe).
+template <typename T, int FM, int EPI, bool DYN>
+__global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int tiles_m, int ntiles, unsigned* sched) {
   using Cfg = PCfg<FM>;
   constexpr int PBM = Cfg::PBM, PBN = Cfg::PBN, NSLOT = Cfg::NSLOT;
   constexpr int A_BYTES = PBM * ROWB, B_BYTES = PBN * ROWB, SLOT_BYTES = A_BYTES + B_BYTES;
@@ -55,19 +62,41 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
   const int l15 = lane & 15, lg = lane >> 4;
   const int nt = g.K / BK;
   const int G = gridDim.x;  // multiple of 8
-  // workgroup -> position inside a round of G consecutive tiles: XCD x takes the x-th eighth
+  // static: workgroup -> position inside a round of G consecutive tiles, XCD x takes the x-th eighth of every round
   const int slot_in_round = (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
   const int my_tiles = slot_in_round < ntiles ? (ntiles - slot_in_round + G - 1) / G : 0;
   const int total_stages = my_tiles * nt;
-  if (total_stages == 0) return;
+  // dynamic: XCD x owns tiles [x_start, x_start + x_len)
+  const int xcd = blockIdx.x & 7, Gx = G >> 3;
+  const int x_start = (int)(((long long)ntiles * xcd) >> 3);
+  const int x_len = (int)(((long long)ntiles * (xcd + 1)) >> 3) - x_start;
+  const int first_tile = (int)(blockIdx.x >> 3) < x_len ? x_start + (int)(blockIdx.x >> 3) : -1;
+  int* s_next = reinterpret_cast<int*>(smem + NSLOT * SLOT_BYTES + 8 * 2048);  // [2] next-tile announcements
+  auto sched_exit = [&]() {   // last workgroup out resets the scheduler state
+    if (tid == 0) {
+      // (no __threadfence here: an agent-scope release writes back the XCD's dirty L2 lines, ~9 us per launch; the
+      //  counters are only ever touched by atomics, and the reset below is ordered by the kernel boundary)
+      if (atomicAdd(&sched[8], 1u) == (unsigned)(G - 1)) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) sched[i] = 0u;
+      }
+    }
+  };
+  if constexpr (DYN) {
+    if (first_tile < 0) {
+      sched_exit();
+      return;
+    }
+  } else {
+    if (total_stages == 0) return;
+  }
 
   const int srow = lane >> 3;
   const int gc = (lane & 7) ^ srow;
   const unsigned lds_base = (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)smem);
   const unsigned wave_off = (unsigned)(wid * 1024);
 
-  auto tile_of = [&](int it, int& m0, int& n0) {
-    const int pid = it * G + slot_in_round;
+  auto tile_of = [&](int pid, int& m0, int& n0) {   // pid = position in the grouped tile order
     constexpr int GM = 8;
     const int per_group = GM * g.tiles_n;
     const int group = pid / per_group, first_m = group * GM;
@@ -81,9 +110,30 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
   const char* ap[Cfg::A_DMA];
   const char* bp[Cfg::B_DMA];
   int l_it = 0, l_k = 0, l_slot = 0;
-  auto set_load_tile = [&](int it) {
+  // dynamic scheduling state (all wave-uniform except `ticket`, which only thread 0 uses)
+  bool l_valid = true;      // the load cursor still has a tile
+  int pending_c = -1;       // tile the compute cursor moves to at its next wrap (-1: none)
+  int c_tile = DYN ? first_tile : slot_in_round;
+  int wraps = 0;            // load-cursor wraps so far (parity selects the s_next entry)
+  unsigned ticket = 0;
+  int ticket_age = -1;      // stages since the draw was issued (-1: none pending)
+  constexpr int PUBLISH_AGE = 3;   // the atomic's round trip under load is longer than one stage: consume it late
+  auto draw = [&]() {       // issue the atomic now, publish its result PUBLISH_AGE stages later
+    if (tid == 0) ticket = atomicAdd(&sched[xcd], 1u);
+    ticket_age = 0;
+  };
+  auto publish = [&]() {    // call before every stage-end barrier
+    if (ticket_age >= 0 && ++ticket_age > PUBLISH_AGE) {
+      if (tid == 0) {
+        const long long idx = (long long)Gx + ticket;
+        s_next[wraps & 1] = idx < x_len ? x_start + (int)idx : -1;
+      }
+      ticket_age = -1;
+    }
+  };
+  auto set_load_tile = [&](int pid) {
     int m0, n0;
-    tile_of(it, m0, n0);
+    tile_of(pid, m0, n0);
 #pragma unroll
     for (int i = 0; i < Cfg::A_DMA; ++i) {
       int ra = m0 + (i * 8 + wid) * 8 + srow;
@@ -107,8 +157,21 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
     l_slot = l_slot == NSLOT - 1 ? 0 : l_slot + 1;
     if (++l_k == nt) {
       l_k = 0;
-      ++l_it;
-      if (l_it < my_tiles) set_load_tile(l_it);
+      if constexpr (DYN) {
+        // the announcement for this wrap was published >= 1 barrier ago (host: nt >= NSLOT + PUBLISH_AGE + 1)
+        const int nxt = __builtin_amdgcn_readfirstlane(s_next[wraps & 1]);
+        ++wraps;
+        pending_c = nxt;
+        if (nxt >= 0) {
+          set_load_tile(nxt);
+          draw();
+        } else {
+          l_valid = false;
+        }
+      } else {
+        ++l_it;
+        if (l_it < my_tiles) set_load_tile(l_it * G + slot_in_round);
+      }
     }
   };
 
@@ -138,10 +201,12 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
       Mma<T>::run(FB[j], FA[i], acc[i][j]);
 
   // prologue: NSLOT-1 stages in flight, wait for stage 0
-  set_load_tile(0);
+  set_load_tile(c_tile);
+  if constexpr (DYN) draw();   // ticket for this workgroup's second tile; published at the end of stage 0
   issue_stage();
-  if (NSLOT > 2 && total_stages > 1) issue_stage();
-  if (NSLOT > 2 && total_stages > 1)
+  const bool two_ahead = NSLOT > 2 && (DYN || total_stages > 1);   // DYN requires nt >= NSLOT + 4 (host check)
+  if (two_ahead) issue_stage();
+  if (two_ahead)
     wait_vmcnt<(NSLOT > 2 ? DPS : 0)>();
   else
     wait_vmcnt<0>();
@@ -152,8 +217,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
   // flight), one barrier.
   int c_it = 0, c_k = 0;
   int slot = 0;
-  for (int s = 0; s < total_stages; ++s) {
-    if (s + NSLOT - 1 < total_stages) issue_stage();
+  for (int s = 0;; ++s) {
+    // a stage is issued at the top of this iteration iff the load cursor still has work
+    const bool issued_now = DYN ? l_valid : (s + NSLOT - 1 < total_stages);
+    if (issued_now) issue_stage();
     {
       // Software-pipelined fragment stream.  The stage is 2*FM "steps" of 4 MFMAs (one A fragment against the
       // four B fragments of its k-half).  All ds_read_b128 are written first, in the order the steps consume
@@ -208,10 +275,10 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
 #undef RA
 #undef RB
     }
-    bool stored = false, full_tile = false;
+    bool stored = false, full_tile = false, more = true;
     if (++c_k == nt) {
       int m0, n0;
-      tile_of(c_it, m0, n0);
+      tile_of(c_tile, m0, n0);
       full_tile = NST > 0 && m0 + PBM <= g.M && n0 + PBN <= g.N;
       {
         char* scratch = smem + NSLOT * SLOT_BYTES + wid * 2048;
@@ -233,46 +300,94 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       c_k = 0;
-      ++c_it;
       stored = true;
+      if constexpr (DYN) {
+        c_tile = pending_c;   // set by the load cursor's wrap, which is always ahead of this one
+        more = c_tile >= 0;
+      } else {
+        ++c_it;
+        c_tile = c_it * G + slot_in_round;
+        more = c_it < my_tiles;
+      }
     }
+    if constexpr (DYN) publish();
     // retire DMA(s+1).  vmcnt counts stores too, in issue order, and the epilogue's stores are younger than
     // every DMA issued so far: after a full tile (a known number of store instructions per wave) wait only
     // for what is older than them, so the write-back drains under the next tile's first stage instead of
     // stalling the whole workgroup on HBM write acknowledgements.
     if (stored) {
-      if (full_tile && s + NSLOT - 1 < total_stages)
+      if (full_tile && issued_now)
         wait_vmcnt<(NSLOT - 2) * DPS + NST>();
       else
         wait_vmcnt<0>();
-    } else if (NSLOT > 2 && s + 2 < total_stages) {
+    } else if (NSLOT > 2 && issued_now) {
       wait_vmcnt<(NSLOT > 2 ? (NSLOT - 2) * DPS : 0)>();
     } else {
       wait_vmcnt<0>();
     }
+    if (!more) break;
     __syncthreads();
     slot = slot == NSLOT - 1 ? 0 : slot + 1;
   }
+  if constexpr (DYN) sched_exit();
 #undef LOAD_FRAGS
 #undef MMA_FRAGS
+}
+
+// Scheduler state for the dynamic mode: 64 slots of 16 counters ([0..7] per-XCD tickets, [8] workgroups finished),
+// a static device array owned by the library; consecutive launches rotate through the slots, and every launch leaves
+// its slot zeroed.
+__device__ unsigned nvit_sched_slots[64][16];
+int g_gemm_sched_dynamic = -1;  // -1: read NVIT_GEMM_SCHED on first use
+
+unsigned* sched_slot() {
+  static unsigned* base[16] = {};
+  static unsigned next = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  if (!base[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(nvit_sched_slots)) != hipSuccess) return nullptr;
+    base[dev] = (unsigned*)p;
+  }
+  return base[dev] + 16 * (next++ & 63);
+}
+
+bool sched_dynamic() {
+  if (g_gemm_sched_dynamic < 0) {
+    const char* e = getenv("NVIT_GEMM_SCHED");
+    g_gemm_sched_dynamic = (e && (e[0] == 'd' || e[0] == '1')) ? 1 : 0;
+  }
+  return g_gemm_sched_dynamic == 1;
 }
 
 template <typename T, int FM, int EPI>
 int launch_p2(const NtArgs& g_in, int n_cu, hipStream_t s) {
   using Cfg = PCfg<FM>;
-  constexpr int LDS_BYTES = Cfg::NSLOT * (Cfg::PBM + Cfg::PBN) * ROWB + 8 * 2048;  // ring + epilogue scratch
+  constexpr int LDS_STATIC = Cfg::NSLOT * (Cfg::PBM + Cfg::PBN) * ROWB + 8 * 2048;  // ring + epilogue scratch
+  constexpr bool CAN_DYN = LDS_STATIC + 16 <= 160 * 1024;   // the 256x128 configuration fills the LDS: static only
+  constexpr int LDS_BYTES = CAN_DYN ? LDS_STATIC + 16 : LDS_STATIC;                 // + s_next
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_persistent_kernel<T, FM, EPI>,
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_persistent_kernel<T, FM, EPI, false>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e == hipSuccess && CAN_DYN)
+      e = hipFuncSetAttribute((const void*)gemm_nt_persistent_kernel<T, FM, EPI, CAN_DYN>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) NVIT_FAIL((int)e, "gemm_nt: cannot raise LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
   }
   NtArgs g = g_in;
   g.tiles_n = cdiv(g.N, Cfg::PBN);
   const int tiles_m = cdiv(g.M, Cfg::PBM);
-  hipLaunchKernelGGL((gemm_nt_persistent_kernel<T, FM, EPI>), dim3(n_cu), dim3(512), LDS_BYTES, s, g, tiles_m,
-                     tiles_m * g.tiles_n);
+  const int nt = g.K / (ROWB / (int)sizeof(T));
+  unsigned* sched = (CAN_DYN && sched_dynamic() && nt >= Cfg::NSLOT + 4) ? sched_slot() : nullptr;
+  if (sched)
+    hipLaunchKernelGGL((gemm_nt_persistent_kernel<T, FM, EPI, CAN_DYN>), dim3(n_cu), dim3(512), LDS_BYTES, s, g, tiles_m,
+                       tiles_m * g.tiles_n, sched);
+  else
+    hipLaunchKernelGGL((gemm_nt_persistent_kernel<T, FM, EPI, false>), dim3(n_cu), dim3(512), LDS_BYTES, s, g, tiles_m,
+                       tiles_m * g.tiles_n, (unsigned*)nullptr);
   NVIT_CHECK_LAUNCH("gemm_nt_persistent");
   return NVIT_OK;
 }
@@ -299,6 +414,12 @@ static int p_num_cu() {
     if (n_cu < 8) n_cu = 8;
   }
   return n_cu;
+}
+
+// scheduling mode of the persistent NT GEMMs: 1 = dynamic tile hand-out (see the kernel comment), 0 = static
+extern "C" int nvit_set_gemm_sched(int dynamic) {
+  g_gemm_sched_dynamic = dynamic ? 1 : 0;
+  return NVIT_OK;
 }
 
 // fused-epilogue launches (bf16 operands, 256x256 tiles): epi = 3 (SwiGLU), 4 (q/k normalise), 5 (SwiGLU backward)
