@@ -432,30 +432,32 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const T* dx, const T* u
 }
 
 // ------------------------------------------------------------------------------ small reductions
-// out[n] = f(sum_b part[b][n]); 256 threads = 32 columns x 8 row groups, fixed summation order
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* part, int nblk, int N, float* out,
-                                                             int accumulate, int kind, const float* ref, float scale) {
-  __shared__ float red[8][33];
+// out[n] = f(sum_b part[b][n]); 1024 threads = 32 columns x 32 row groups, fixed summation order (the partial arrays
+// are a few MB and there are only N/32 workgroups, so the kernel is latency-bound: many short rows per thread)
+constexpr int CSR_RG = 32;
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, int nblk, int N, float* out,
+                                                              int accumulate, int kind, const float* ref, float scale) {
+  __shared__ float red[CSR_RG][33];
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int n = blockIdx.x * 32 + cl;
   float s = 0.f;
   if (n < N) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int b = rg;
-    for (; b + 24 < nblk; b += 32) {
+    for (; b + 3 * CSR_RG < nblk; b += 4 * CSR_RG) {
       s0 += part[(size_t)b * N + n];
-      s1 += part[(size_t)(b + 8) * N + n];
-      s2 += part[(size_t)(b + 16) * N + n];
-      s3 += part[(size_t)(b + 24) * N + n];
+      s1 += part[(size_t)(b + CSR_RG) * N + n];
+      s2 += part[(size_t)(b + 2 * CSR_RG) * N + n];
+      s3 += part[(size_t)(b + 3 * CSR_RG) * N + n];
     }
-    for (; b < nblk; b += 8) s0 += part[(size_t)b * N + n];
+    for (; b < nblk; b += CSR_RG) s0 += part[(size_t)b * N + n];
     s = (s0 + s1) + (s2 + s3);
   }
   red[rg][cl] = s;
   __syncthreads();
   if (rg != 0 || n >= N) return;
 #pragma unroll
-  for (int g = 1; g < 8; ++g) s += red[g][cl];
+  for (int g = 1; g < CSR_RG; ++g) s += red[g][cl];
   if (kind == 1) {
     const float r = ref[n] * scale;
     s = s * (r > 0.f ? scale : (r < 0.f ? -scale : 0.f));
@@ -477,13 +479,31 @@ __global__ void colsum_kernel(const TA* a, int lda, const TB* b, int ldb, int R,
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int rc = blockIdx.y;
   if (n >= N) return;
-  float s = 0.f;
-  for (int r = rc; r < R; r += period) {
+  // four independent partial sums (fixed order): four loads in flight per thread instead of a dependent chain
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = rc;
+  for (; r + 3 * period < R; r += 4 * period) {
+    float v0 = ld1<TA>(a + (size_t)r * lda + n);
+    float v1 = ld1<TA>(a + (size_t)(r + period) * lda + n);
+    float v2 = ld1<TA>(a + (size_t)(r + 2 * period) * lda + n);
+    float v3 = ld1<TA>(a + (size_t)(r + 3 * period) * lda + n);
+    if (b) {
+      v0 *= ld1<TB>(b + (size_t)r * ldb + n);
+      v1 *= ld1<TB>(b + (size_t)(r + period) * ldb + n);
+      v2 *= ld1<TB>(b + (size_t)(r + 2 * period) * ldb + n);
+      v3 *= ld1<TB>(b + (size_t)(r + 3 * period) * ldb + n);
+    }
+    s0 += v0;
+    s1 += v1;
+    s2 += v2;
+    s3 += v3;
+  }
+  for (; r < R; r += period) {
     float v = ld1<TA>(a + (size_t)r * lda + n);
     if (b) v *= ld1<TB>(b + (size_t)r * ldb + n);
-    s += v;
+    s0 += v;
   }
-  s *= scale;
+  float s = ((s0 + s1) + (s2 + s3)) * scale;
   float* o = out + (size_t)rc * N + n;
   *o = accumulate ? *o + s : s;
 }
@@ -671,7 +691,7 @@ extern "C" int nvit_colsum_reduce(const float* part, int nblk, int N, float* out
                                   const float* ref, float scale, void* stream) {
   NVIT_REQUIRE(kind == 0 || (kind == 1 && ref) || (kind == 2 && N % 32 == 0), "colsum_reduce: bad kind");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 32)), dim3(256), 0, s, part, nblk, N, out, accumulate, kind,
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 32)), dim3(1024), 0, s, part, nblk, N, out, accumulate, kind,
                      ref, scale);
   NVIT_CHECK_LAUNCH("colsum_reduce");
   return NVIT_OK;
