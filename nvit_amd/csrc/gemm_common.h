@@ -70,6 +70,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_off) {
 // 16-byte non-temporal global store.  GEMM outputs are written once and read by a LATER kernel; storing them with
 // the nt policy keeps them from evicting the A/B operand tiles that the next tiles of THIS kernel re-read from L2
 // (measured on 256x256 tiles: -7 % (bf16 out) / -10 % (fp32 out) per tile at K = 1536, -1..3 % at K = 768).
+__device__ __forceinline__ uint4 ld16_nt(const void* p) {
+  typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
+  return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_*>(p)));
+}
 __device__ __forceinline__ void st16_nt(void* p, const uint4& v) {
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
   __builtin_nontemporal_store(__builtin_bit_cast(u32x4_, v), reinterpret_cast<u32x4_*>(p));
@@ -179,11 +183,11 @@ __device__ __forceinline__ void nt_store_tile_staged(const NtArgs& g, f32x4 (&ac
           if (g.accumulate) {
             if constexpr (EO == 4) {
               f32x4 v = __builtin_bit_cast(f32x4, raw);
-              v += *reinterpret_cast<const f32x4*>(cp);
+              v += __builtin_bit_cast(f32x4, ld16_nt(cp));
               st16_nt(cp, __builtin_bit_cast(uint4, v));
             } else {
               const bf16x8 nv = __builtin_bit_cast(bf16x8, raw);
-              const bf16x8 ov = *reinterpret_cast<const bf16x8*>(cp);
+              const bf16x8 ov = __builtin_bit_cast(bf16x8, ld16_nt(cp));
               bf16x8 r;
 #pragma unroll
               for (int e = 0; e < 8; ++e) r[e] = (bf16)((float)nv[e] + (float)ov[e]);
