@@ -1,0 +1,18 @@
+"""Fused-epilogue GEMMs of the Base config (SwiGLU forward, SwiGLU backward, q/k normalise), HIP-event timed."""
+import sys, os, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from nvit_amd import ops
+from gemm_bench import bench
+
+dev = "cuda:0"
+M, C = 100352, 768
+x = torch.randn(M, C, device=dev).bfloat16()
+wfc = (torch.randn(8 * C, C, device=dev) * 0.03).bfloat16()
+suv = torch.ones(8 * C, device=dev)
+ms, tf = bench(lambda: ops.gemm_nt_swiglu(x, wfc, M, 4 * C, C, suv, math.sqrt(C)), 2.0 * M * 8 * C * C, iters=20)
+print(f"EPI3 fc + SwiGLU        : {ms:.3f} ms {tf:7.1f} TF/s", flush=True)
+uv, xm = ops.gemm_nt_swiglu(x, wfc, M, 4 * C, C, suv, math.sqrt(C))
+wpt = (torch.randn(4 * C, C, device=dev) * 0.03).bfloat16()
+ms, tf = bench(lambda: ops.gemm_nt_swiglu_bwd(x, wpt, uv, M, 4 * C, C, suv, math.sqrt(C)), 2.0 * M * 4 * C * C, iters=20)
+print(f"EPI5 p.Wt + SwiGLU bwd  : {ms:.3f} ms {tf:7.1f} TF/s", flush=True)
