@@ -428,3 +428,34 @@ def test_base_config_full_size_vs_cpu_oracle():
     eb = (lb.cpu() - logits_ref).abs().max().item()
     print(f"   bf16 mode max|dlogit| vs the fp32 oracle {eb:.3e}")
     assert eb < 5e-3
+
+
+def test_checkpoint_resume_is_exact(tmp_path):
+    """Reference checkpoint dict (train.py:640-650) through nvit_amd.checkpoint: 2 steps, save, load into a fresh
+    model + FusedAdamW, 1 more step == 3 uninterrupted steps, bit for bit (weights, AdamW moments, step counter)."""
+    from nvit_amd.checkpoint import load_checkpoint, save_checkpoint
+    from nvit_amd.train import train_step
+    cfg = named_config("micro")
+    X, y = synthetic_batch(cfg, 8)
+    X, y = X.cuda(), y.cuda()
+    mk_opt = lambda mm: mm.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")
+    a = build(cfg, "bf16", True)
+    oa = mk_opt(a)
+    for _ in range(3):
+        train_step(a, oa, X, y)
+    b = build(cfg, "bf16", True)
+    ob = mk_opt(b)
+    for _ in range(2):
+        train_step(b, ob, X, y)
+    path = save_checkpoint(tmp_path / "checkpoint_latest.pt", b, ob, 2, {"val/loss": 0.0, "train/loss": 0.0})
+    c, oc, ck = load_checkpoint(path, device="cuda", optimizer_factory=mk_opt, trusted=True)
+    c.set_precision("bf16").train()
+    assert ck["iter_num"] == 2
+    train_step(c, oc, X, y)
+    for (n, pa), (_, pc) in zip(a.named_parameters(), c.named_parameters()):
+        assert torch.equal(pa, pc), n
+    sa, sc = oa.state_dict()["state"], oc.state_dict()["state"]
+    assert sa.keys() == sc.keys()
+    for k in sa:
+        assert float(sa[k]["step"]) == float(sc[k]["step"]) == 3.0
+        assert torch.equal(sa[k]["exp_avg"], sc[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sc[k]["exp_avg_sq"])
