@@ -177,8 +177,10 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
   }
   __syncthreads();
   int cur = 0;
-  // the last tile may be ragged: only that instantiation carries the key mask (peeled, so the steady-state tiles
-  // spend no VALU on compares/selects)
+  // Ragged sequence lengths (T = 784 = 6.125 x 128 = 12.25 x 64): a wave whose 32 queries all lie past Tq only feeds the
+  // K/V ring and the barriers (wave_active), and the ragged last KV tile - peeled, so the steady-state tiles spend no
+  // VALU on masks - multiplies and exponentiates only its valid 16-key fragments (nkf) / 32-key MFMA steps (ns2).
+  const bool wave_active = q0 < Tq;
   auto tile_body = [&](const int t, auto masked_) {
     constexpr bool MASKED = decltype(masked_)::value;
     if (t + 2 < nt) {
@@ -186,69 +188,81 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
       tile_dma(kbase, D, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid);
       tile_dma(vbase, D, (t + 2) * TKV, Tk, ring + (2 * sl + 1) * TILE_BYTES, lane, wid);
     }
-    const char* kt = &lds[cur][0][0];
-    const char* vt = &lds[cur][1][0];
-    // S^T[kf][f] : rows = key 16kf + 4lg + r, col = query 16f + l15
-    f32x4 s[4][2];
+    if (wave_active) {
+      const char* kt = &lds[cur][0][0];
+      const char* vt = &lds[cur][1][0];
+      const int kbase_i = t * TKV;
+      const int nvalid = MASKED ? Tk - kbase_i : TKV;
+      const int nkf = MASKED ? (nvalid + 15) >> 4 : 4, ns2 = MASKED ? (nvalid + 31) >> 5 : 2;
+      // S^T[kf][f] : rows = key 16kf + 4lg + r, col = query 16f + l15
+      f32x4 s[4][2];
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf) {
-      const uint4 a0 = row_frag(kt, kf * 16, 0, l15, lg), a1 = row_frag(kt, kf * 16, 1, l15, lg);
+      for (int kf = 0; kf < 4; ++kf) {
+        if (!MASKED || kf < nkf) {
+          const uint4 a0 = row_frag(kt, kf * 16, 0, l15, lg), a1 = row_frag(kt, kf * 16, 1, l15, lg);
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            z = mfma16(a0, qf[f][0], z);
+            s[kf][f] = mfma16(a1, qf[f][1], z);
+          }
+          if constexpr (MASKED) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (kf * 16 + lg * 4 + r >= nvalid) {
+                s[kf][0][r] = -INFINITY;
+                s[kf][1][r] = -INFINITY;
+              }
+          }
+        } else {
+          s[kf][0] = (f32x4){0.f, 0.f, 0.f, 0.f};   // fragment past the end: probability 0, no work
+          s[kf][1] = s[kf][0];
+        }
+      }
+      uint4 pf[2][2];  // [s2][f]
 #pragma unroll
       for (int f = 0; f < 2; ++f) {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        z = mfma16(a0, qf[f][0], z);
-        s[kf][f] = mfma16(a1, qf[f][1], z);
+        float mt = -INFINITY;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+          if (!MASKED || kf < nkf) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[kf][f][r]);
+          }
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float mn = fmaxf(m_[f], mt);
+        const float corr = fast_exp2((m_[f] - mn) * c2);
+        m_[f] = mn;
+        const float mc = mn * c2;
+        float rs = 0.f;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+          if (!MASKED || kf < nkf) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float p = fast_exp2(s[kf][f][r] * c2 - mc);
+              s[kf][f][r] = p;
+              rs += p;
+            }
+          }
+        l_[f] = l_[f] * corr + rs;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) oacc[i][f] = oacc[i][f] * corr;
+        pf[0][f] = pack8(s[0][f], s[1][f]);
+        pf[1][f] = pack8(s[2][f], s[3][f]);
       }
-    }
-    const int kbase_i = t * TKV;
-    if constexpr (MASKED) {
+      // O^T[df][f] += V^T P^T
 #pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
+      for (int df = 0; df < 4; ++df)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (kbase_i + kf * 16 + lg * 4 + r >= Tk) {
-            s[kf][0][r] = -INFINITY;
-            s[kf][1][r] = -INFINITY;
+        for (int s2 = 0; s2 < 2; ++s2)
+          if (!MASKED || s2 < ns2) {
+            const uint4 va = tr_frag(vt, s2 * 32, df * 16, l15, lg);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) oacc[df][f] = mfma16(va, pf[s2][f], oacc[df][f]);
           }
     }
-    uint4 pf[2][2];  // [s2][f]
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      float mt = -INFINITY;
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mt = fmaxf(mt, s[kf][f][r]);
-      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      const float mn = fmaxf(m_[f], mt);
-      const float corr = fast_exp2((m_[f] - mn) * c2);
-      m_[f] = mn;
-      const float mc = mn * c2;
-      float rs = 0.f;
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = fast_exp2(s[kf][f][r] * c2 - mc);
-          s[kf][f][r] = p;
-          rs += p;
-        }
-      l_[f] = l_[f] * corr + rs;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) oacc[i][f] = oacc[i][f] * corr;
-      pf[0][f] = pack8(s[0][f], s[1][f]);
-      pf[1][f] = pack8(s[2][f], s[3][f]);
-    }
-    // O^T[df][f] += V^T P^T
-#pragma unroll
-    for (int df = 0; df < 4; ++df)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const uint4 va = tr_frag(vt, s2 * 32, df * 16, l15, lg);
-#pragma unroll
-        for (int f = 0; f < 2; ++f) oacc[df][f] = mfma16(va, pf[s2][f], oacc[df][f]);
-      }
     if (t + 2 < nt)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else
@@ -416,6 +430,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
   }
   __syncthreads();
   int cur = 0;
+  const bool wave_active = q0 < Tq;   // see the forward kernel
   auto tile_body = [&](const int t, auto masked_) {
     constexpr bool MASKED = decltype(masked_)::value;
     if (t + 2 < nt) {
@@ -423,46 +438,58 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
       tile_dma(kbase, D, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid);
       tile_dma(vbase, D, (t + 2) * TKV, Tk, ring + (2 * sl + 1) * TILE_BYTES, lane, wid);
     }
-    const char* kt = &lds[cur][0][0];
-    const char* vt = &lds[cur][1][0];
-    const int kbase_i = t * TKV;
-    uint4 dsf[2][2];  // [s2][f]
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      f32x4 ds_[2][2];  // [kk][f] for key frags kf = 2*s2 + kk
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int kf = 2 * s2 + kk;
-        const uint4 a0 = row_frag(kt, kf * 16, 0, l15, lg), a1 = row_frag(kt, kf * 16, 1, l15, lg);
-        const uint4 v0 = row_frag(vt, kf * 16, 0, l15, lg), v1 = row_frag(vt, kf * 16, 1, l15, lg);
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          z = mfma16(a0, qf[f][0], z);
-          z = mfma16(a1, qf[f][1], z);  // S^T
-          f32x4 w = {0.f, 0.f, 0.f, 0.f};
-          w = mfma16(v0, gf[f][0], w);
-          w = mfma16(v1, gf[f][1], w);  // dP^T
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const bool valid = !MASKED || (kbase_i + kf * 16 + lg * 4 + r) < Tk;
-            const float p = valid ? fast_exp2(z[r] * c2 - lse2[f]) : 0.f;
-            ds_[kk][f][r] = p * (w[r] - dl[f]) * scale;
-          }
-        }
-      }
-#pragma unroll
-      for (int f = 0; f < 2; ++f) dsf[s2][f] = pack8(ds_[0][f], ds_[1][f]);
-    }
-    // dQ^T[df][f] += K^T dS^T
-#pragma unroll
-    for (int df = 0; df < 4; ++df)
+    if (wave_active) {
+      const char* kt = &lds[cur][0][0];
+      const char* vt = &lds[cur][1][0];
+      const int kbase_i = t * TKV;
+      const int nvalid = MASKED ? Tk - kbase_i : TKV;
+      const int nkf = MASKED ? (nvalid + 15) >> 4 : 4, ns2 = MASKED ? (nvalid + 31) >> 5 : 2;
+      uint4 dsf[2][2];  // [s2][f]
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        const uint4 ka = tr_frag(kt, s2 * 32, df * 16, l15, lg);
+        if (!MASKED || s2 < ns2) {
+          f32x4 ds_[2][2];  // [kk][f] for key frags kf = 2*s2 + kk
 #pragma unroll
-        for (int f = 0; f < 2; ++f) dq[df][f] = mfma16(ka, dsf[s2][f], dq[df][f]);
+          for (int kk = 0; kk < 2; ++kk) {
+            const int kf = 2 * s2 + kk;
+            if (!MASKED || kf < nkf) {
+              const uint4 a0 = row_frag(kt, kf * 16, 0, l15, lg), a1 = row_frag(kt, kf * 16, 1, l15, lg);
+              const uint4 v0 = row_frag(vt, kf * 16, 0, l15, lg), v1 = row_frag(vt, kf * 16, 1, l15, lg);
+#pragma unroll
+              for (int f = 0; f < 2; ++f) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                z = mfma16(a0, qf[f][0], z);
+                z = mfma16(a1, qf[f][1], z);  // S^T
+                f32x4 w = {0.f, 0.f, 0.f, 0.f};
+                w = mfma16(v0, gf[f][0], w);
+                w = mfma16(v1, gf[f][1], w);  // dP^T
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  const bool valid = !MASKED || (kf * 16 + lg * 4 + r) < nvalid;
+                  const float p = valid ? fast_exp2(z[r] * c2 - lse2[f]) : 0.f;
+                  ds_[kk][f][r] = p * (w[r] - dl[f]) * scale;
+                }
+              }
+            } else {
+              ds_[kk][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+              ds_[kk][1] = ds_[kk][0];
+            }
+          }
+#pragma unroll
+          for (int f = 0; f < 2; ++f) dsf[s2][f] = pack8(ds_[0][f], ds_[1][f]);
+        }
       }
+      // dQ^T[df][f] += K^T dS^T
+#pragma unroll
+      for (int df = 0; df < 4; ++df)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+          if (!MASKED || s2 < ns2) {
+            const uint4 ka = tr_frag(kt, s2 * 32, df * 16, l15, lg);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) dq[df][f] = mfma16(ka, dsf[s2][f], dq[df][f]);
+          }
+    }
     if (t + 2 < nt)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else
