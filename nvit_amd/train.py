@@ -12,10 +12,7 @@ with a plain torch optimizer the three steps run separately, same result.
 """
 from __future__ import annotations
 
-from typing import Optional
-
 import torch
-import torch.nn.functional as F
 
 from . import ops
 from .optim import FusedAdamW
