@@ -459,3 +459,31 @@ def test_checkpoint_resume_is_exact(tmp_path):
     for k in sa:
         assert float(sa[k]["step"]) == float(sc[k]["step"]) == 3.0
         assert torch.equal(sa[k]["exp_avg"], sc[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sc[k]["exp_avg_sq"])
+
+
+def test_large_config_full_size_vs_cpu_oracle():
+    """BASELINE config C4 (nViT-Large/16: C=1024, H=16, L=24) at full model size, one image, against the CPU oracle:
+    fp32 mode inside the 1e-5 logits bar, bf16 mode bounded; then one fused optimizer step keeps rows/columns unit."""
+    from nvit_amd.train import train_step
+    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    cfg = named_config("large")
+    X, y = synthetic_batch(cfg, 1)
+    p, logits_ref, loss_ref, _ = oracle_run(cfg, X, y, True)
+    m = build(cfg, "fp32", True).train()
+    with torch.no_grad():
+        logits, _ = m(X.cuda())
+    err = (logits.cpu() - logits_ref).abs().max().item()
+    print(f"[large vs oracle] fp32 mode max|dlogit| {err:.3e} (|logit|max {logits_ref.abs().max().item():.3f})")
+    assert err < 1e-5
+    m.set_precision("bf16")
+    with torch.no_grad():
+        lb, _ = m(X.cuda())
+    eb = (lb.cpu() - logits_ref).abs().max().item()
+    print(f"   bf16 mode max|dlogit| vs the fp32 oracle {eb:.3e}")
+    assert eb < 8e-3
+    opt = m.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")
+    _, loss, _, gnorm = train_step(m, opt, X.cuda(), y.cuda(), 1.0)
+    assert torch.isfinite(loss).item() and torch.isfinite(gnorm).item()
+    blk = m.transformer.h[-1]
+    assert (blk.c_fc.weight.detach().norm(dim=1) - 1).abs().max().item() < 1e-5
+    assert (blk.mlp_c_proj.weight.detach().norm(dim=0) - 1).abs().max().item() < 1e-5
