@@ -127,6 +127,10 @@ int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int ldb, void* C
 /* Tile scheduling of the persistent NT GEMM kernels: 0 = static round-robin (default, or NVIT_GEMM_SCHED=static),
  * 1 = dynamic per-XCD ticket counters (NVIT_GEMM_SCHED=dynamic): robust when other kernels (RCCL) hold some CUs. */
 int nvit_set_gemm_sched(int dynamic);
+/* Kernel selection for tests / experiments (-1 = environment default).  nt_impl: 0 = 128x128 kernel only,
+ * 1 = persistent 256-row kernels for large problems (default), 2 = persistent kernels whatever the tile count;
+ * tn_impl: 0 = 128x128 kernel only, 1 = persistent 256x256 kernel for eligible shapes (default). */
+int nvit_set_gemm_impl(int nt_impl, int tn_impl);
 int nvit_gemm_nt_fusable(int dt, int M, int N, int K);
 int nvit_gemm_nt_swiglu_bwd(int dt, const void* A, int lda, const void* B, int ldb, const void* uv, void* duv,
                             float* part, int M, int F, int K, const float* gs, float gscale, void* stream);
@@ -161,6 +165,7 @@ int nvit_lerp_bwd(int dt, const float* dout, const float* h, const void* y, int 
                   void* stream);
 
 /* Block.norm_skip on its own (model.py:84-87): out = nrm(src*skip[0] + tgt), fp32 [M,C]; backward writes dsrc, dtgt
+ * (tgt == NULL / dtgt == NULL: the target term is absent, i.e. justnorm(src*skip[0]), model.py:43-44,89-90)
  * and part_dskip [nblk]. (ViT.forward uses the copy fused into nvit_lerp_fwd/bwd.) */
 int nvit_norm_skip_fwd(const float* src, const float* tgt, const float* skip, float* out, int M, int C, void* stream);
 int nvit_norm_skip_bwd(const float* dout, const float* src, const float* tgt, const float* skip, float* dsrc,

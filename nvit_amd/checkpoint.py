@@ -7,8 +7,10 @@
   A checkpoint written by the reference loads here and vice versa (`Trainer.load_checkpoint`, train.py:375-395).
 * `out/stat` row: `Trainer.write_statistics` / `get_hparams_str` (train.py:1037-1072), same fields and formatting.
 
-Files are read with `weights_only=True` first (tensors, numbers, strings, dicts only); a checkpoint that needs the
-pickled numpy RNG tuple falls back to a full load only when `trusted=True` is passed.
+Files are read with `weights_only=True` (nothing from the file is executed): tensors, numbers, strings, containers,
+plus the three numpy reconstruction globals that the `rng_state_numpy` tuple (`np.random.get_state()`) pickles to,
+allow-listed for this load only.  A file that still does not load that way is refused unless `trusted=True`, which
+falls back to a full unpickle - only for files you wrote yourself.
 """
 from __future__ import annotations
 
@@ -24,8 +26,19 @@ from .config import ViTConfig
 
 
 def _model_state(model) -> Dict[str, torch.Tensor]:
+    """The reference's `model.state_dict()` key set, including the Kohonen maps' persistent index buffers
+    `locations` / `offsets` (kohonen.py:62,78): `Trainer.load_checkpoint` loads it with strict=True."""
     m = model.module if hasattr(model, "module") else model
-    return {k: v for k, v in m.state_dict().items() if not k.endswith((".locations", ".offsets"))}
+    return dict(m.state_dict())
+
+
+def _numpy_safe_globals():
+    """Globals a pickled `np.random.get_state()` tuple refers to (array reconstruction only, no code)."""
+    from numpy._core import multiarray as ma
+    allow = [ma._reconstruct, np.ndarray, np.dtype, type(np.dtype(np.uint32))]
+    # files written under numpy 1.x name the same function through the old module path
+    allow.append((ma._reconstruct, "numpy.core.multiarray._reconstruct"))
+    return allow
 
 
 def build_checkpoint(model, optimizer, iter_num: int, metrics: Dict[str, float], config: Optional[Dict[str, Any]] = None,
@@ -57,10 +70,12 @@ def load_checkpoint(path, device="cuda", optimizer_factory=None, restore_rng: bo
     then restored (e.g. `lambda m: m.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")`)."""
     from .model import ViT
     try:
-        ck = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception:
+        with torch.serialization.safe_globals(_numpy_safe_globals()):
+            ck = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:
         if not trusted:
-            raise RuntimeError(f"{path}: not loadable with weights_only=True; pass trusted=True for a file you wrote")
+            raise RuntimeError(f"{path}: not loadable with weights_only=True ({type(e).__name__}); pass trusted=True "
+                               "only for a file you wrote yourself") from e
         ck = torch.load(path, map_location="cpu", weights_only=False)
     model = ViT(ViTConfig(**ck["model_args"]))
     res = model.load_state_dict(ck["model"], strict=False)
@@ -75,7 +90,7 @@ def load_checkpoint(path, device="cuda", optimizer_factory=None, restore_rng: bo
     if restore_rng:
         if "rng_state_pytorch" in ck and ck["rng_state_pytorch"] is not None:
             torch.set_rng_state(ck["rng_state_pytorch"].cpu())
-        if trusted and ck.get("rng_state_numpy") is not None:
+        if ck.get("rng_state_numpy") is not None:
             np.random.set_state(ck["rng_state_numpy"])
     return model, opt, ck
 

@@ -346,6 +346,17 @@ __global__ void slab_reduce_kernel(const float* ws, int splits, int N, int K, fl
 
 }  // namespace
 
+// Kernel selection (tests and experiments; -1 = read NVIT_GEMM_NT_IMPL / NVIT_GEMM_TN_IMPL on first use).
+// nt: 0 = always the 128x128 kernel, 1 = persistent kernels for large problems (default), 2 = persistent kernels
+// whatever the tile count.  tn: 0 = always the 128x128 kernel, 1 = persistent kernel for eligible shapes (default).
+static int g_nt_impl = -1, g_tn_impl = -1;
+extern "C" int nvit_set_gemm_impl(int nt_impl, int tn_impl) {
+  NVIT_REQUIRE(nt_impl >= -1 && nt_impl <= 2 && tn_impl >= -1 && tn_impl <= 1, "set_gemm_impl: nt in -1..2, tn in -1..1");
+  g_nt_impl = nt_impl;
+  g_tn_impl = tn_impl;
+  return NVIT_OK;
+}
+
 extern "C" int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int out_dt,
                             int M, int N, int K, const float* bias, const float* colscale, const float* rowadd,
                             int rowadd_period, int accumulate, void* stream) {
@@ -384,13 +395,16 @@ extern "C" int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int l
   {
     // large problems: persistent kernels (gemm_p.hip), 256x256 tiles when N allows, else 256x128.
     // NVIT_GEMM_NT_IMPL=0 forces the 128x128 kernel, NVIT_GEMM_NT_TILE=128|256 forces a tile width.
-    static int impl = -1, force_tile = 0;
-    if (impl < 0) {
+    static int force_tile = -1;
+    if (g_nt_impl < 0) {
       const char* e = getenv("NVIT_GEMM_NT_IMPL");
-      impl = e ? atoi(e) : 1;
+      g_nt_impl = e ? atoi(e) : 1;
+    }
+    if (force_tile < 0) {
       const char* t = getenv("NVIT_GEMM_NT_TILE");
       force_tile = t ? atoi(t) : 0;
     }
+    const int impl = g_nt_impl;
     if (impl >= 1) {  // 2: persistent kernel whatever the tile count (experiments)
       const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 256), t128 = (long long)cdiv(M, 256) * cdiv(N, 128);
       int tile = 0;
@@ -460,12 +474,11 @@ extern "C" int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int l
   bool done = false;
   {
     // big 256-aligned weight shapes: persistent 256x256 kernel (gemm_tn_p.hip); NVIT_GEMM_TN_IMPL=0 disables
-    static int impl = -1;
-    if (impl < 0) {
+    if (g_tn_impl < 0) {
       const char* e = getenv("NVIT_GEMM_TN_IMPL");
-      impl = e ? atoi(e) : 1;
+      g_tn_impl = e ? atoi(e) : 1;
     }
-    if (impl == 1 && Mred >= 4096) {
+    if (g_tn_impl == 1 && Mred >= 4096) {
       const int rc = nvit_gemm_tn_persistent_launch(dt, A, lda, B, ldb, ws, g.zeros, Mred, N, K,
                                                     splits, s);
       if (rc > 0) return rc;

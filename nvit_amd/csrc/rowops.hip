@@ -216,9 +216,14 @@ __global__ __launch_bounds__(256) void norm_skip_fwd_kernel(const float* src, co
   for (int m = blockIdx.x * ROW_WAVES + wid; m < M; m += gridDim.x * ROW_WAVES) {
     RowVec<NV> a, b;
     row_load<NV, float>(a, src + (size_t)m * C, C, lane);
-    row_load<NV, float>(b, tgt + (size_t)m * C, C, lane);
+    if (tgt) {   // tgt == NULL: plain justnorm(source * skip)
+      row_load<NV, float>(b, tgt + (size_t)m * C, C, lane);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) a.v[i] = a.v[i] * sk + b.v[i];
+      for (int i = 0; i < NV; ++i) a.v[i] = a.v[i] * sk + b.v[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) a.v[i] = a.v[i] * sk;
+    }
     const float rs = 1.0f / sqrtf(row_dot<NV>(a, a));
 #pragma unroll
     for (int i = 0; i < NV; ++i) a.v[i] = a.v[i] * rs;
@@ -237,7 +242,12 @@ __global__ __launch_bounds__(256) void norm_skip_bwd_kernel(const float* dout, c
   for (int m = blockIdx.x * ROW_WAVES + wid; m < M; m += gridDim.x * ROW_WAVES) {
     RowVec<NV> a, b, g;
     row_load<NV, float>(a, src + (size_t)m * C, C, lane);
-    row_load<NV, float>(b, tgt + (size_t)m * C, C, lane);
+    if (tgt) {
+      row_load<NV, float>(b, tgt + (size_t)m * C, C, lane);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) b.v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     row_load<NV, float>(g, dout + (size_t)m * C, C, lane);
 #pragma unroll
     for (int i = 0; i < NV; ++i) b.v[i] = a.v[i] * sk + b.v[i];
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(256) void norm_skip_bwd_kernel(const float* dout, c
 #pragma unroll
     for (int i = 0; i < NV; ++i) g.v[i] = (g.v[i] - b.v[i] * og) * rs;  // d(source*skip + target)
     acc += row_dot<NV>(g, a);
-    row_store<NV, float>(g, dtgt + (size_t)m * C, C, lane);
+    if (dtgt) row_store<NV, float>(g, dtgt + (size_t)m * C, C, lane);
 #pragma unroll
     for (int i = 0; i < NV; ++i) g.v[i] = g.v[i] * sk;
     row_store<NV, float>(g, dsrc + (size_t)m * C, C, lane);

@@ -99,6 +99,16 @@ class KohonenMap(nn.Module):
                    [-self.m, self.n], [self.m, -self.n]]
         self.register_buffer("offsets", torch.tensor(offsets))
 
+    def get_neighborhood_distances(self, bmu_loc: Tensor) -> Tensor:
+        """Squared grid distance of every node to `bmu_loc` ([2]: row, col) on the periodic map: the minimum over the
+        un-shifted grid and its 8 wrapped copies (reference kohonen.py:80-98).  Index arithmetic on [m*n, 2] integers
+        (the SOM update kernel recomputes the same quantity per node in registers, kohonen.hip); returns fp32 [m*n]."""
+        loc = self.locations.float()
+        bmu = bmu_loc.to(loc.device).float().reshape(1, 2)
+        shifts = torch.cat((torch.zeros(1, 2, device=loc.device), self.offsets.float()), dim=0)   # [9, 2]
+        d = loc.unsqueeze(0) + shifts.unsqueeze(1) - bmu.unsqueeze(0)                              # [9, m*n, 2]
+        return (d * d).sum(-1).min(dim=0).values
+
     def forward(self, x: Tensor) -> Tuple[Tensor, Tensor]:
         """x [..., C] -> (node representations [..., C], winning indices [...])."""
         if not x.is_cuda:

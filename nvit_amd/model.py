@@ -570,6 +570,34 @@ class _NormSkipFn(torch.autograd.Function):
         return ops.norm_skip_bwd(dout.contiguous(), source, target, skip)
 
 
+class _JustNormFn(torch.autograd.Function):
+    """x / ||x||_2 over the last axis (reference model.py:43-44), rows of up to 2048 fp32 values."""
+
+    @staticmethod
+    def forward(ctx, x2):
+        one = torch.ones(1, device=x2.device, dtype=torch.float32)
+        ctx.save_for_backward(x2, one)
+        return ops.norm_skip_fwd(x2, None, one)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, one = ctx.saved_tensors
+        return ops.norm_skip_bwd(dout.contiguous(), x2, None, one)[0]
+
+
+def justnorm(x: Tensor) -> Tensor:
+    """Module-level `justnorm` of the reference (model.py:43-44): x / x.norm(p=2, dim=-1, keepdim=True), no eps.
+    Inside ViT.forward the normalisations are fused into the LERP / q-k / GEMM-epilogue kernels; this entry point is
+    for callers that use it on its own.  HIP device only (no CPU path); the result has x's dtype."""
+    if not x.is_cuda:
+        raise RuntimeError("nvit_amd.justnorm runs only on the HIP device (no CPU fallback)")
+    D = x.shape[-1]
+    if D % 4 != 0 or D > 2048:
+        raise ValueError(f"justnorm: last dimension must be a multiple of 4 and <= 2048 (got {D})")
+    out = _JustNormFn.apply(x.reshape(-1, D).contiguous().float())
+    return out.reshape(x.shape).to(x.dtype)
+
+
 class _ReconFn(torch.autograd.Function):
     """reconstruction head + loss: mean((tanh(x W_r^T + b_r) - local patches)^2) (reference model.py:459-464)."""
 
@@ -653,7 +681,8 @@ class Block(nn.Module):
         return out.reshape(shp)
 
     def justnorm(self, x: Tensor) -> Tensor:
-        raise NotImplementedError("justnorm is fused into the HIP kernels; it has no standalone entry point here")
+        """Reference model.py:89-90."""
+        return justnorm(x)
 
     def forward(self, h: Tensor) -> Tensor:
         """h [B,T,C] -> [B,T,C] (block output BEFORE norm_skip, like the reference)."""
@@ -748,6 +777,7 @@ class ViT(nn.Module):
         self.attn_impl = os.environ.get("NVIT_ATTN_IMPL", "auto")
         object.__setattr__(self, "_rt", _Runtime(self))
         object.__setattr__(self, "_node_sync", None)   # set by DataParallel: averages SOM nodes across ranks
+        object.__setattr__(self, "_taps", None)        # tests: dict that receives the residual stream after each block
         object.__setattr__(self.cross_attention, "_owner", self)
         for i, blk in enumerate(self.transformer.h):
             object.__setattr__(blk, "_owner", (self, i))
@@ -834,7 +864,9 @@ class ViT(nn.Module):
 
     # ---- Kohonen helpers (reference model.py:477-561), same names and semantics
     def combine_representations(self, local_repr: Tensor, global_repr: Tensor) -> Tensor:
-        raise NotImplementedError("combine_representations is only used by the reference's debug visualisation")
+        """Element-wise product, then unit L2 norm over the channel axis (reference model.py:477-480; used by its
+        debug visualisation only).  The product is one multiply; the normalisation is the justnorm row kernel."""
+        return justnorm(local_repr * global_repr)
 
     def compute_consistency_loss(self, local_repr: Tensor, global_repr: Tensor) -> Tensor:
         Cc = local_repr.shape[-1]
@@ -901,8 +933,13 @@ class ViT(nn.Module):
             x, x_lo = self.cross_attention._run(local_new, global_new)
         else:
             x, x_lo = self.cross_attention._run(loc, glo)
-        for blk in self.transformer.h:
+        taps = self._taps
+        if taps is not None:
+            taps["loc"], taps["glo"], taps["x0"] = loc.detach(), glo.detach(), x.detach()
+        for i, blk in enumerate(self.transformer.h):
             x, x_lo = blk._run(x, x_lo, True)
+            if taps is not None:
+                taps[f"x{i + 1}"] = x.detach()
         logits = _HeadFn.apply(x, rt, self.mlp_head[0].weight, self.mlp_head[0].bias, self.mlp_head[1].weight,
                                self.mlp_head[1].bias, self.sz)
         aux["reconstruction"] = _ReconFn.apply(x, x_lo, rt, img, self.reconstruction_head[0].weight,

@@ -207,17 +207,19 @@ def lerp_bwd(dt: int, dout: Tensor, h: Tensor, y: Tensor, alpha: Tensor, c_a: fl
     return dh, dy, dy_lo, dskip_x, part, pskip
 
 
-def norm_skip_fwd(src: Tensor, tgt: Tensor, skip: Tensor) -> Tensor:
+def norm_skip_fwd(src: Tensor, tgt: Optional[Tensor], skip: Tensor) -> Tensor:
+    """nrm(src*skip + tgt); tgt None = justnorm(src*skip)."""
     M, Cc = src.shape
     out = torch.empty_like(src)
     check(_lib.load().nvit_norm_skip_fwd(_p(src), _p(tgt), _p(skip), _p(out), M, Cc, _s()), "nvit_norm_skip_fwd")
     return out
 
 
-def norm_skip_bwd(dout: Tensor, src: Tensor, tgt: Tensor, skip: Tensor):
+def norm_skip_bwd(dout: Tensor, src: Tensor, tgt: Optional[Tensor], skip: Tensor):
     M, Cc = src.shape
     nblk = min(PART_BLOCKS, math.ceil(M / 4))
-    dsrc, dtgt = torch.empty_like(src), torch.empty_like(src)
+    dsrc = torch.empty_like(src)
+    dtgt = torch.empty_like(src) if tgt is not None else None
     part = torch.empty((nblk,), device=src.device, dtype=torch.float32)
     check(_lib.load().nvit_norm_skip_bwd(_p(dout), _p(src), _p(tgt), _p(skip), _p(dsrc), _p(dtgt), _p(part), nblk, M,
                                          Cc, _s()), "nvit_norm_skip_bwd")

@@ -25,8 +25,11 @@ def test_checkpoint_roundtrip_and_reference_keys(tmp_path):
     assert isinstance(raw["rng_state_numpy"], tuple) and raw["rng_state_pytorch"].dtype == torch.uint8
     # every reference state_dict key is there, and nothing private (operand shadows) leaks out
     assert set(raw["model"]) == set(formula_state_dict(cfg))
-    m2, opt2, ck = load_checkpoint(path, device="cpu", trusted=True,
+    # default load path: weights_only (nothing from the file is executed), including the numpy RNG tuple
+    np.random.seed(123)
+    m2, opt2, ck = load_checkpoint(path, device="cpu",
                                    optimizer_factory=lambda mm: mm.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cpu"))
+    assert np.array_equal(np.random.get_state()[1], raw["rng_state_numpy"][1])   # numpy RNG restored without trusted=True
     for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
         assert torch.equal(a, b), k
     assert ck["metrics"]["val/loss"] == 1.5 and opt2 is not None
@@ -34,3 +37,54 @@ def test_checkpoint_roundtrip_and_reference_keys(tmp_path):
     fields = row.split()
     assert fields[0] == "1.700000e+01" and fields[1] == "1.0000e-03" and fields[4:13] == ["0.0:.4e"] * 9
     assert len(fields) == 13 + 1 + 4 * cfg.n_layer
+
+
+def test_kohonen_checkpoint_has_the_reference_state_dict_keys(tmp_path):
+    """A use_kohonen checkpoint carries the maps' persistent buffers `locations` / `offsets` (reference kohonen.py:62,78;
+    SURVEY.md §9.5), so the reference's strict load_state_dict accepts it; and it loads back here weights-only."""
+    from nvit_amd.checkpoint import load_checkpoint, save_checkpoint
+    from nvit_amd.model import ViT
+    cfg = named_config("micro_k")
+    m = ViT(cfg)
+    m.load_state_dict(formula_state_dict(cfg), strict=False)
+    opt = m.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cpu")
+    path = save_checkpoint(tmp_path / "ck.pt", m, opt, 3, {"val/loss": 0.0, "train/loss": 0.0})
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    want = set(formula_state_dict(cfg)) | {f"{k}_kohonen.{b}" for k in ("local", "global") for b in ("locations", "offsets")}
+    assert set(raw["model"]) == want
+    assert raw["model"]["local_kohonen.locations"].dtype == torch.int64
+    assert tuple(raw["model"]["local_kohonen.offsets"].shape) == (8, 2)
+    m2, _, _ = load_checkpoint(path, device="cpu")
+    assert torch.equal(m2.local_kohonen.locations, m.local_kohonen.locations)
+    assert torch.equal(m2.global_kohonen.nodes, m.global_kohonen.nodes)
+
+
+class _Weird:   # a global that is not on the weights-only allow list
+    pass
+
+
+def test_untrusted_pickle_is_refused(tmp_path):
+    """A file that needs arbitrary unpickling is not loaded unless the caller says it wrote it."""
+    import pytest
+    from nvit_amd.checkpoint import load_checkpoint
+
+    path = tmp_path / "bad.pt"
+    torch.save({"model": {}, "model_args": {}, "x": _Weird()}, path)
+    with pytest.raises(RuntimeError):
+        load_checkpoint(path, device="cpu")
+
+
+def test_public_helpers_present():
+    """API the reference exposes and callers may reach (model.py:43-44,89-90,477-480; kohonen.py:80-98)."""
+    from nvit_amd import model as M
+    from nvit_amd.kohonen import KohonenMap
+    assert callable(M.justnorm) and callable(M.Block.justnorm) and callable(M.ViT.combine_representations)
+    km = KohonenMap(8, 16)
+    d = km.get_neighborhood_distances(torch.tensor([0, 3]))
+    # periodic 4x4 grid: node (0,3) itself 0; (0,0) is one step away through the wrap; (2,1) is 2 rows, 2 cols away
+    assert d.shape == (16,) and d[3].item() == 0.0 and d[0].item() == 1.0 and d[2 * 4 + 1].item() == 8.0
+    # against the oracle's restatement of kohonen.py:80-98
+    from oracle import nvit_oracle as O
+    for loc in ([0, 0], [1, 2], [3, 3]):
+        assert torch.equal(km.get_neighborhood_distances(torch.tensor(loc)),
+                           O.som_neighborhood_d2(torch.tensor(loc), km.m, km.n))
