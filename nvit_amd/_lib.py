@@ -32,6 +32,7 @@ SIGNATURES = {
     "nvit_adamw_tick": [_vp, C.c_double, C.c_double, _vp],
     "nvit_set_gemm_sched": [_i],
     "nvit_set_gemm_impl": [_i, _i],
+    "nvit_set_tn_order": [_i],
     "nvit_ce_loss": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "nvit_gemm_nt": [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp],
     "nvit_gemm_nt_fusable": [_i, _i, _i, _i],

@@ -263,6 +263,13 @@ __global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
 
 }  // namespace
 
+// item deal of the persistent weight-gradient kernel: 1 = XCD-contiguous (default), 0 = round-robin (A/B measurements)
+static int g_tn_order = -1;
+extern "C" int nvit_set_tn_order(int xcd_contiguous) {
+  g_tn_order = xcd_contiguous ? 1 : 0;
+  return NVIT_OK;
+}
+
 // Returns NVIT_OK after launching, or a negative value (-1) when the shape is not eligible.
 int nvit_gemm_tn_persistent_launch(int dt, const void* A, int lda, const void* B, int ldb, float* ws,
                                    const float* zeros, int Mred, int N, int K, int splits, hipStream_t s) {
@@ -302,8 +309,8 @@ int nvit_gemm_tn_persistent_launch(int dt, const void* A, int lda, const void* B
   g.rows_per_split = rps;
   g.tiles_n = N / TBN;
   g.tiles_k = K / TBK;
-  static const int order = getenv("NVIT_TN_ORDER") ? atoi(getenv("NVIT_TN_ORDER")) : 1;
-  g.xcd_order = order;
+  if (g_tn_order < 0) g_tn_order = getenv("NVIT_TN_ORDER") ? atoi(getenv("NVIT_TN_ORDER")) : 1;
+  g.xcd_order = g_tn_order;
   const int nitems = g.tiles_n * g.tiles_k * splits;
   const int grid = nitems < n_cu ? nitems : n_cu;
   if (dt == NVIT_BF16)

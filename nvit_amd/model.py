@@ -92,6 +92,17 @@ class _Runtime:
         with torch.cuda.stream(self.side):
             return fn()
 
+    def grad_buf(self, params, shape) -> Tensor:
+        """Destination of a parameter gradient: the data-parallel wrapper's flat bucket slice when it offers one
+        (`model._grad_sink`, parallel.py: gradients are produced in place, nothing is copied), else a fresh tensor.
+        `params`: the parameter, or the parameters whose gradients one GEMM writes stacked along dim 0."""
+        sink = self.model._grad_sink
+        if sink is not None:
+            t = sink(params, shape)
+            if t is not None:
+                return t
+        return torch.empty(shape, device=params[0].device, dtype=torch.float32)
+
     def join(self) -> None:
         if self.use_side and self.side is not None:
             ev = torch.cuda.Event()
@@ -188,14 +199,14 @@ def _attn_part_fwd(rt: _Runtime, impl: int, q_src, ldq, k_src, ldk, v_src, ldv, 
     return qh, kh, vh, rq, rk, o, lse
 
 
-def _param_grad_alpha(part: Tensor, alpha: Tensor, c_a: float) -> Tensor:
-    g = torch.empty_like(alpha)
+def _param_grad_alpha(rt, part: Tensor, alpha: Tensor, c_a: float) -> Tensor:
+    g = rt.grad_buf((alpha,), alpha.shape)
     ops.colsum_reduce(part, g, False, kind=1, ref=alpha, scale=c_a)
     return g
 
 
-def _param_grad_scaled(part: Tensor, like: Tensor, scale: float) -> Tensor:
-    g = torch.empty_like(like)
+def _param_grad_scaled(rt, part: Tensor, like: Tensor, scale: float) -> Tensor:
+    g = rt.grad_buf((like,), like.shape)
     ops.colsum_reduce(part, g, False, kind=0, scale=scale)
     return g
 
@@ -264,6 +275,7 @@ class _BlockFn(torch.autograd.Function):
             xn_lo = xn.new_empty(0)  # placeholder: callers alias x itself in fp32 mode (see _lo())
         ctx.rt, ctx.idx, ctx.with_skip, ctx.impl, ctx.has_b = rt, idx, with_skip, impl, has_b
         ctx.dims = (B, T, C, H, d, M)
+        ctx.par = (skip_param, attn_alpha, mlp_alpha, sqk, suv, wq, wk, wv, wo, wfc, wp)   # gradient destinations
         ctx.save_for_backward(x, x_lo, qh, kh, vh, rq, rk, o, lse, y, h1, h1_lo, uv, xm, y2, skip_param, attn_alpha,
                               mlp_alpha, sqk, suv)
         ctx.mark_non_differentiable(xn_lo)
@@ -276,6 +288,7 @@ class _BlockFn(torch.autograd.Function):
          suv) = ctx.saved_tensors
         rt, idx, impl = ctx.rt, ctx.idx, ctx.impl
         B, T, C, H, d, M = ctx.dims
+        p_skip, p_aalpha, p_malpha, p_sqk, p_suv, p_wq, p_wk, p_wv, p_wo, p_wfc, p_wp = ctx.par
         cfg = rt.model.config
         dt, td = rt.dt, ops.tdtype(rt.dt)
         sh = rt.sh
@@ -288,13 +301,13 @@ class _BlockFn(torch.autograd.Function):
         if ctx.with_skip:
             dh1, _, dy2_lo, dx, part_lam, part_skip = ops.lerp_bwd(dt, dxn, h1, y2, mlp_alpha, c_a, x, skip_param,
                                                                    None, False, False, True)
-            dskip = torch.empty_like(skip_param)
+            dskip = rt.grad_buf((p_skip,), p_skip.shape)
             ops.colsum_reduce(part_skip, dskip, False)
         else:
             dh1, _, dy2_lo, _, part_lam, _ = ops.lerp_bwd(dt, dxn, h1, y2, mlp_alpha, c_a, None, None, None, False,
                                                           False, True)
             dx, dskip = None, None
-        d_mlp_alpha = _param_grad_alpha(part_lam, mlp_alpha, c_a)
+        d_mlp_alpha = _param_grad_alpha(rt, part_lam, p_malpha, c_a)
         gscale = math.sqrt(C)
         if ops.fusable(dt, M, 4 * C, C):
             # data gradient of mlp_c_proj with the SwiGLU backward in the GEMM epilogue (dx_mlp never reaches HBM)
@@ -302,12 +315,12 @@ class _BlockFn(torch.autograd.Function):
         else:
             dxm = ops.gemm_nt(dy2_lo, sh[pre + "p.Wt"], M, 4 * C, C, out_dtype=td)
             duv, part_suv = ops.swiglu_bwd(dt, dxm, uv, suv, gscale, M, 4 * C)
-        g_wp = torch.empty((C, 4 * C), device=x.device, dtype=torch.float32)
+        g_wp = rt.grad_buf((p_wp,), (C, 4 * C))
         rt.on_side(lambda: ops.gemm_tn(dy2_lo, xm, g_wp, M, C, 4 * C), dy2_lo, xm)
         g_bp = _bias_grad(dy2_lo, M, C) if ctx.has_b else None
-        d_suv = _param_grad_scaled(part_suv, suv, 1.0)
+        d_suv = _param_grad_scaled(rt, part_suv, p_suv, 1.0)
         ops.gemm_nt(duv, sh[pre + "fc.Wt"], M, C, 8 * C, out=dh1, accumulate=True)
-        g_wfc = torch.empty((8 * C, C), device=x.device, dtype=torch.float32)
+        g_wfc = rt.grad_buf((p_wfc,), (8 * C, C))
         rt.on_side(lambda: ops.gemm_tn(duv, h1_lo, g_wfc, M, 8 * C, C, perm=1), duv, h1_lo)
         g_bfc = _bias_grad(duv, M, 8 * C, perm=1) if ctx.has_b else None
         # ---- attention half
@@ -317,9 +330,9 @@ class _BlockFn(torch.autograd.Function):
         else:
             dx, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dh1, x, y, attn_alpha, c_a, None, None, dx, True, False,
                                                         True)
-        d_attn_alpha = _param_grad_alpha(part_lam, attn_alpha, c_a)
+        d_attn_alpha = _param_grad_alpha(rt, part_lam, p_aalpha, c_a)
         do = ops.gemm_nt(dy_lo, sh[pre + "o.Wt"], M, C, C, out_dtype=td)
-        g_wo = torch.empty((C, C), device=x.device, dtype=torch.float32)
+        g_wo = rt.grad_buf((p_wo,), (C, C))
         rt.on_side(lambda: ops.gemm_tn(dy_lo, o, g_wo, M, C, C), dy_lo, o)
         g_bo = _bias_grad(dy_lo, M, C) if ctx.has_b else None
         dqkv = torch.empty((M, 3 * C), device=x.device, dtype=td)
@@ -327,15 +340,15 @@ class _BlockFn(torch.autograd.Function):
             # attention backward with the q/k-normalise backward fused into its epilogues
             part_q, part_k = ops.attn_bwd_qknorm(do, qh, kh, vh, o, lse, math.sqrt(d), rq, rk, sqk, c_q, dqkv, 3 * C,
                                                  dqkv[:, C:], dqkv[:, 2 * C:], 3 * C)
-            d_sqk = _param_grad_scaled(part_q, sqk, c_q)
+            d_sqk = _param_grad_scaled(rt, part_q, p_sqk, c_q)
             ops.colsum_reduce(part_k, d_sqk, True, kind=0, scale=c_q)
         else:
             dqh, dkh, dvh = ops.attn_bwd(dt, impl, do, qh, kh, vh, o, lse, math.sqrt(d))
             part_sqk = ops.qknorm_bwd(dt, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q, dqkv, 3 * C, dqkv[:, C:], 3 * C,
                                       dqkv[:, 2 * C:], 3 * C, B, T, H, d)
-            d_sqk = _param_grad_scaled(part_sqk, sqk, c_q)
+            d_sqk = _param_grad_scaled(rt, part_sqk, p_sqk, c_q)
         ops.gemm_nt(dqkv, sh[pre + "qkv.Wt"], M, C, 3 * C, out=dx, accumulate=True)
-        g_qkv = torch.empty((3 * C, C), device=x.device, dtype=torch.float32)
+        g_qkv = rt.grad_buf((p_wq, p_wk, p_wv), (3 * C, C))   # one stacked GEMM output = three adjacent bucket slices
         rt.on_side(lambda: ops.gemm_tn(dqkv, x_lo, g_qkv, M, 3 * C, C), dqkv, x_lo)
         g_bqkv = _bias_grad(dqkv, M, 3 * C) if ctx.has_b else None
         rt.join()
@@ -389,6 +402,7 @@ class _CrossFn(torch.autograd.Function):
             x_lo = x.new_empty(0)
         ctx.rt, ctx.impl, ctx.has_b = rt, impl, has_b
         ctx.dims = (B, T, C, H, d, M)
+        ctx.par = (attn_alpha, sqk, wq, wk, wv, wproj, wout)
         ctx.save_for_backward(loc, glo, loc_lo, glo_lo, qh, kh, vh, rq, rk, o, lse, pr, g, y, attn_alpha, sqk)
         ctx.mark_non_differentiable(x_lo)
         ctx.set_materialize_grads(False)
@@ -401,6 +415,7 @@ class _CrossFn(torch.autograd.Function):
         loc, glo, loc_lo, glo_lo, qh, kh, vh, rq, rk, o, lse, pr, g, y, attn_alpha, sqk = ctx.saved_tensors
         rt, impl = ctx.rt, ctx.impl
         B, T, C, H, d, M = ctx.dims
+        p_alpha, p_sqk, p_wq, p_wk, p_wv, p_wproj, p_wout = ctx.par
         cfg = rt.model.config
         dt, td = rt.dt, ops.tdtype(rt.dt)
         sh = rt.sh
@@ -408,33 +423,33 @@ class _CrossFn(torch.autograd.Function):
         c_q, c_a = 1.0 / cfg.base_scale, 0.05 / cfg.base_scale
         dloc, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dx.contiguous(), loc, y, attn_alpha, c_a, None, None, None,
                                                       False, False, True)
-        d_alpha = _param_grad_alpha(part_lam, attn_alpha, c_a)
+        d_alpha = _param_grad_alpha(rt, part_lam, p_alpha, c_a)
         if ops.fusable(dt, M, C, C):
             dpr, _ = ops.gemm_nt_swiglu_bwd(dy_lo, sh["x.out.Wt"], pr, M, C, C, None, 1.0)
         else:
             dg = ops.gemm_nt(dy_lo, sh["x.out.Wt"], M, C, C, out_dtype=td)
             dpr, _ = ops.swiglu_bwd(dt, dg, pr, None, 1.0, M, C)
-        g_wout = ops.gemm_tn(dy_lo, g, torch.empty((C, C), device=dev, dtype=torch.float32), M, C, C)
+        g_wout = ops.gemm_tn(dy_lo, g, rt.grad_buf((p_wout,), (C, C)), M, C, C)
         g_bout = _bias_grad(dy_lo, M, C) if ctx.has_b else None
         do = ops.gemm_nt(dpr, sh["x.proj.Wt"], M, C, 2 * C, out_dtype=td)
-        g_wproj = ops.gemm_tn(dpr, o, torch.empty((2 * C, C), device=dev, dtype=torch.float32), M, 2 * C, C, perm=1)
+        g_wproj = ops.gemm_tn(dpr, o, rt.grad_buf((p_wproj,), (2 * C, C)), M, 2 * C, C, perm=1)
         g_bproj = _bias_grad(dpr, M, 2 * C, perm=1) if ctx.has_b else None
         dq = torch.empty((M, C), device=dev, dtype=td)
         dkv = torch.empty((M, 2 * C), device=dev, dtype=td)
         if impl == 1 and d == 64 and dt != F32:
             part_q, part_k = ops.attn_bwd_qknorm(do, qh, kh, vh, o, lse, math.sqrt(d), rq, rk, sqk, c_q, dq, C, dkv,
                                                  dkv[:, C:], 2 * C)
-            d_sqk = _param_grad_scaled(part_q, sqk, c_q)
+            d_sqk = _param_grad_scaled(rt, part_q, p_sqk, c_q)
             ops.colsum_reduce(part_k, d_sqk, True, kind=0, scale=c_q)
         else:
             dqh, dkh, dvh = ops.attn_bwd(dt, impl, do, qh, kh, vh, o, lse, math.sqrt(d))
             part_sqk = ops.qknorm_bwd(dt, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q, dq, C, dkv, 2 * C, dkv[:, C:],
                                       2 * C, B, T, H, d)
-            d_sqk = _param_grad_scaled(part_sqk, sqk, c_q)
+            d_sqk = _param_grad_scaled(rt, part_sqk, p_sqk, c_q)
         ops.gemm_nt(dq, sh["x.q.Wt"], M, C, C, out=dloc, accumulate=True)
         dglo = ops.gemm_nt(dkv, sh["x.kv.Wt"], M, C, 2 * C, out_dtype=torch.float32)
-        g_wq = ops.gemm_tn(dq, loc_lo, torch.empty((C, C), device=dev, dtype=torch.float32), M, C, C)
-        g_wkv = ops.gemm_tn(dkv, glo_lo, torch.empty((2 * C, C), device=dev, dtype=torch.float32), M, 2 * C, C)
+        g_wq = ops.gemm_tn(dq, loc_lo, rt.grad_buf((p_wq,), (C, C)), M, C, C)
+        g_wkv = ops.gemm_tn(dkv, glo_lo, rt.grad_buf((p_wk, p_wv), (2 * C, C)), M, 2 * C, C)
         if ctx.has_b:
             g_bq = _bias_grad(dq, M, C)
             g_bkv = _bias_grad(dkv, M, 2 * C)
@@ -483,6 +498,7 @@ class _EmbedFn(torch.autograd.Function):
                               rowadd=posg.reshape(T, C), rowadd_period=T)
         ctx.rt = rt
         ctx.dims = (B, T, C, M, Kl, Kg)
+        ctx.par = (wl, wg)
         ctx.shapes = (wl.shape, wg.shape, posl.shape)
         ctx.save_for_backward(A_l, A_g)
         return loc, glo
@@ -494,10 +510,10 @@ class _EmbedFn(torch.autograd.Function):
         B, T, C, M, Kl, Kg = ctx.dims
         dev = A_l.device
         out = []
-        for dy, A, K in ((dloc, A_l, Kl), (dglo, A_g, Kg)):
+        for dy, A, K, pw in ((dloc, A_l, Kl, ctx.par[0]), (dglo, A_g, Kg, ctx.par[1])):
             dy = dy.contiguous()
             dy_lo = dy if rt.dt == F32 else ops.cast(dy, rt.dt)
-            gw = ops.gemm_tn(dy_lo, A[:, :K], torch.empty((C, K), device=dev, dtype=torch.float32), M, C, K)
+            gw = ops.gemm_tn(dy_lo, A[:, :K], rt.grad_buf((pw,), (C, K)), M, C, K)
             dpos = torch.empty((T, C), device=dev, dtype=torch.float32)
             ops.colsum(dy, M, C, dpos, False, period=T)
             db = torch.empty((C,), device=dev, dtype=torch.float32)
@@ -778,6 +794,7 @@ class ViT(nn.Module):
         object.__setattr__(self, "_rt", _Runtime(self))
         object.__setattr__(self, "_node_sync", None)   # set by DataParallel: averages SOM nodes across ranks
         object.__setattr__(self, "_taps", None)        # tests: dict that receives the residual stream after each block
+        object.__setattr__(self, "_grad_sink", None)   # set by DataParallel: gradients are produced inside its buckets
         object.__setattr__(self.cross_attention, "_owner", self)
         for i, blk in enumerate(self.transformer.h):
             object.__setattr__(blk, "_owner", (self, i))
@@ -796,6 +813,15 @@ class ViT(nn.Module):
                 nn.init.zeros_(mod.bias)
         with torch.no_grad():
             self.sz.fill_(self.config.sz_init_value)
+
+    def _stacked_grads(self):
+        """Weights whose gradients leave ONE weight-gradient GEMM stacked along dim 0, in that GEMM's row order (the
+        data-parallel wrapper lays them out adjacently so the GEMM writes the bucket directly)."""
+        ca = self.cross_attention
+        groups = [(ca.k_global.weight, ca.v_global.weight)]
+        for blk in self.transformer.h:
+            groups.append((blk.query.weight, blk.key.weight, blk.value.weight))
+        return groups
 
     # ---- runtime helpers
     def set_precision(self, precision: str) -> "ViT":

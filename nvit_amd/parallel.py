@@ -15,7 +15,13 @@ Design (MI355X: 8 GPUs, fully connected xGMI mesh, 7 links/GPU):
   * parameters that never receive a gradient (rmsnorm_* weights, reconstruction head without the
     Kohonen loss, SURVEY.md §9.1-Q6) are detected on the first backward and left out of the buckets;
   * `no_sync()` suppresses communication for gradient-accumulation micro-steps;
-  * after the collective, `p.grad` is re-pointed at its slice of the reduced flat bucket (no copy back).
+  * after the collective, `p.grad` is re-pointed at its slice of the reduced flat bucket (no copy back);
+  * gradients are PRODUCED in the buckets where possible ("gradient as bucket view"): the model's backward asks
+    `module._grad_sink` for the destination of a weight gradient and the weight-gradient GEMM writes straight into
+    the bucket slice, so the post-accumulate hook finds `p.grad` already in place and copies nothing.  Slices
+    start on 16-byte boundaries (the fused optimizer and the norm kernel read gradients as float4);
+  * the q/k/v (and cross-attention k/v) weights are laid out adjacently in GEMM row order inside their bucket, so the
+    one stacked [3C, C] weight-gradient GEMM output IS the three bucket slices.
 Works with any backend of torch.distributed ("nccl" = RCCL on ROCm; "gloo" for the CPU tests).
 """
 from __future__ import annotations
@@ -28,18 +34,25 @@ import torch.distributed as dist
 from torch import nn
 
 
+_ALIGN = 4   # elements: every slice of a flat fp32 bucket starts on a 16-byte boundary
+
+
 class _Bucket:
     def __init__(self, params: List[nn.Parameter]):
         self.params = params
-        self.numel = sum(p.numel() for p in params)
         self.offsets = []
         off = 0
         for p in params:
             self.offsets.append(off)
-            off += p.numel()
+            off += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN   # padding elements stay zero (allocated with zeros)
+        self.numel = off
         self.flat: Optional[torch.Tensor] = None
         self.pending = 0
         self.handle = None
+
+    def slice_of(self, i: int) -> torch.Tensor:
+        p = self.params[i]
+        return self.flat[self.offsets[i]: self.offsets[i] + p.numel()].view_as(p)
 
 
 class DataParallel(nn.Module):
@@ -58,6 +71,8 @@ class DataParallel(nn.Module):
         self._callback_queued = False
         self._first_done = False
         self._seen = set()
+        self._issued = set()
+        self.copies = 0   # gradients copied into a bucket by the hook (0 per step once the gradient sink is active)
         if broadcast_parameters:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -93,6 +108,7 @@ class DataParallel(nn.Module):
             torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
 
     def _hook(self, p: nn.Parameter) -> None:
+        self._issued.discard(p)   # its gradient has been accumulated: p.grad is set from here on
         if not self._sync:
             return
         self._queue_callback()
@@ -104,9 +120,11 @@ class DataParallel(nn.Module):
             self._late.append(p)
             return
         i = b.index[p]
-        sl = b.flat[b.offsets[i]: b.offsets[i] + p.numel()].view_as(p)
-        sl.copy_(p.grad)
-        p.grad = sl
+        sl = b.slice_of(i)
+        if p.grad.data_ptr() != sl.data_ptr():   # not produced in place by the gradient sink: copy in
+            sl.copy_(p.grad)
+            p.grad = sl
+            self.copies += 1
         b.pending -= 1
         if b.pending == 0:
             self._launch(b)
@@ -115,8 +133,46 @@ class DataParallel(nn.Module):
         b.flat.div_(self.world)
         b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def _build_buckets(self) -> None:
+    def _ordered_used(self) -> List[nn.Parameter]:
+        """Reverse registration order (= the order backward produces gradients in), except that weights whose gradients
+        come out of ONE stacked GEMM are placed adjacently in that GEMM's row order (`module._stacked_grads()`)."""
         used = [p for p in reversed(self._params) if p in self._seen]
+        groups = getattr(self.module, "_stacked_grads", lambda: [])()
+        pos = {p: i for i, p in enumerate(used)}
+        for grp in groups:
+            ids = {id(q) for q in grp}
+            if not all(q in pos for q in grp):
+                continue
+            first = min(pos[q] for q in grp)
+            rest = [q for q in used if id(q) not in ids]
+            n_before = sum(1 for q in used[:first] if id(q) not in ids)
+            used = rest[:n_before] + list(grp) + rest[n_before:]
+            pos = {p: i for i, p in enumerate(used)}
+        return used
+
+    def _sink(self, params, shape) -> Optional[torch.Tensor]:
+        """Destination for the gradient of `params` (one parameter, or several whose gradients one GEMM produces
+        stacked along dim 0): a view of the flat bucket, or None when the gradient must go to a fresh tensor (buckets
+        not built yet, a gradient is already being accumulated, parameters not adjacent)."""
+        if self._buckets is None:
+            return None
+        b = self._bucket_of.get(params[0])
+        # a slice is handed out once per backward pass (a weight used several times per forward - the cross-attention
+        # block under the Kohonen head - produces several partial gradients; only one of them may live in the bucket)
+        if b is None or any(q.grad is not None or q in self._issued for q in params):
+            return None
+        i0 = b.index[params[0]]
+        off = b.offsets[i0]
+        n = 0
+        for k, q in enumerate(params):
+            if self._bucket_of.get(q) is not b or b.index[q] != i0 + k or b.offsets[i0 + k] != off + n:
+                return None
+            n += q.numel()
+        self._issued.update(params)
+        return b.flat[off: off + n].view(shape)
+
+    def _build_buckets(self) -> None:
+        used = self._ordered_used()
         buckets: List[_Bucket] = []
         cur: List[nn.Parameter] = []
         size = 0
@@ -136,6 +192,8 @@ class DataParallel(nn.Module):
             for p in b.params:
                 self._bucket_of[p] = b
         self._buckets = buckets
+        if hasattr(self.module, "_grad_sink"):
+            object.__setattr__(self.module, "_grad_sink", self._sink)
 
     def _end_of_backward(self) -> None:
         self._callback_queued = False
@@ -146,7 +204,7 @@ class DataParallel(nn.Module):
             self._late = []
             for b in self._buckets:
                 for i, p in enumerate(b.params):
-                    sl = b.flat[b.offsets[i]: b.offsets[i] + p.numel()].view_as(p)
+                    sl = b.slice_of(i)
                     sl.copy_(p.grad)
                     p.grad = sl
                 self._launch(b)
@@ -154,8 +212,10 @@ class DataParallel(nn.Module):
             if b.handle is None and b.pending != len(b.params) and b.pending != 0:
                 # some gradients of this bucket were not produced this step: treat them as zeros
                 for i, p in enumerate(b.params):
-                    if p.grad is None or p.grad.data_ptr() != b.flat[b.offsets[i]:].data_ptr():
-                        b.flat[b.offsets[i]: b.offsets[i] + p.numel()].zero_()
+                    # (a gradient produced in place this step already sits in its slice: only the missing ones are
+                    #  zeroed; p.grad is None for those after zero_grad(set_to_none=True))
+                    if p.grad is None:
+                        b.slice_of(i).zero_()
                 self._launch(b)
         for p in self._late:
             p.grad.div_(self.world)

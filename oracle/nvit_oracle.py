@@ -29,8 +29,10 @@ golden vectors produced by importing the real reference on CPU
 including the known-answer record of SURVEY.md §9.3.
 
 `lowp` hook: when not None it is applied to every GEMM operand (activations and
-weights) and to the softmax probabilities, emulating "bf16 MFMA operands, fp32
-accumulate" so the bf16 HIP path can be compared at a tight tolerance.
+weights) and to the un-normalised softmax probabilities exp(s - rowmax) (the
+operand a fused attention kernel feeds its second product), emulating "bf16 MFMA
+operands, fp32 accumulate" so the bf16 HIP path can be compared at a tight
+tolerance.  With lowp=None nothing changes (plain softmax; pinned by the goldens).
 """
 from __future__ import annotations
 
@@ -96,8 +98,14 @@ def attend(q: Tensor, k: Tensor, v: Tensor, s_eff: Tensor, H: int, lowp: LowP) -
     kh = s * nrm(heads(k, H))
     vh = heads(v, H)
     scores = (_lp(qh, lowp) @ _lp(kh, lowp).transpose(-1, -2)) * math.sqrt(d)
-    p = torch.softmax(scores, dim=-1)
-    o = _lp(p, lowp) @ _lp(vh, lowp)
+    if lowp is None:
+        o = torch.softmax(scores, dim=-1) @ vh
+    else:
+        # bf16-operand emulation: the second product's low-precision operand is the UN-normalised probability
+        # exp(s - rowmax), as in every fused (flash-style) attention kernel incl. the reference's SDPA under autocast;
+        # the row sum that normalises the output is taken in fp32 from the unrounded values
+        pt = torch.exp(scores - scores.max(dim=-1, keepdim=True).values)
+        o = (lowp(pt) @ lowp(vh)) / pt.sum(dim=-1, keepdim=True)
     return o.permute(0, 2, 1, 3).reshape(B, T, C)
 
 

@@ -13,17 +13,52 @@ import torch.multiprocessing as mp
 from torch import nn
 
 
+class _StackedLinear(torch.autograd.Function):
+    """y = x @ cat(w1, w2)^T with the two weight gradients produced by ONE stacked product, written into the
+    destination the data-parallel wrapper offers (the pattern of the q/k/v weight-gradient GEMM in nvit_amd/model.py)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, owner):
+        ctx.save_for_backward(x, w1, w2)
+        ctx.par, ctx.owner = (w1, w2), owner
+        return x @ torch.cat((w1, w2), dim=0).t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1, w2 = ctx.saved_tensors
+        n1 = w1.shape[0]
+        sink = ctx.owner._grad_sink
+        shape = (w1.shape[0] + w2.shape[0], w1.shape[1])
+        g = sink(ctx.par, shape) if sink is not None else None
+        if g is None:
+            g = torch.empty(shape)
+        else:
+            ctx.owner.sunk += 1
+        torch.mm(dy.t(), x, out=g)
+        return dy @ torch.cat((w1, w2), dim=0), g[:n1], g[n1:], None
+
+
 class Net(nn.Module):
     def __init__(self):
         super().__init__()
         torch.manual_seed(0)
         self.a = nn.Linear(16, 64)
         self.unused = nn.Parameter(torch.ones(7))          # never receives a gradient (like rmsnorm_*)
-        self.b = nn.Linear(64, 300)
+        self.odd = nn.Parameter(torch.ones(1))             # 1-element parameter (like skip_param): slices must stay aligned
+        self.w2 = nn.Parameter(torch.randn(20, 64) * 0.1)  # registered BEFORE w1: the wrapper must re-order the pair
+        self.w1 = nn.Parameter(torch.randn(12, 64) * 0.1)
+        self.b = nn.Linear(32, 300)
         self.c = nn.Linear(300, 5)
+        self._grad_sink = None
+        self.sunk = 0
+
+    def _stacked_grads(self):
+        return [(self.w1, self.w2)]
 
     def forward(self, x):
-        return self.c(torch.tanh(self.b(torch.tanh(self.a(x)))))
+        h = torch.tanh(self.a(x)) * self.odd
+        h = _StackedLinear.apply(h, self.w1, self.w2, self)
+        return self.c(torch.tanh(self.b(torch.tanh(h))))
 
 
 def _data():
@@ -50,7 +85,7 @@ def _worker(rank, world, port, out):
             with torch.no_grad():
                 for p in net.parameters():
                     p.add_(1.0)
-        dp = DataParallel(net, bucket_cap_mb=0.05)  # tiny cap -> several buckets
+        dp = DataParallel(net, bucket_cap_mb=0.02)  # tiny cap -> several buckets
         X, y = _data()
         xs, ys = X.chunk(world)[rank], y.chunk(world)[rank]
         res = {}
@@ -60,6 +95,10 @@ def _worker(rank, world, port, out):
             nn.functional.cross_entropy(dp(xs), ys).backward()
             res[f"step{step}"] = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
         res["buckets"] = dp.num_buckets
+        res["sunk"] = net.sunk
+        res["copies"] = dp.copies
+        res["aligned"] = all(p.grad.data_ptr() % 16 == 0 for p in net.parameters() if p.grad is not None)
+        res["w_adjacent"] = net.w2.grad.data_ptr() == net.w1.grad.data_ptr() + net.w1.numel() * 4
         # gradient accumulation: 2 micro-steps, only the last one communicates
         for p in net.parameters():
             p.grad = None
@@ -85,6 +124,10 @@ def test_dataparallel_gloo_world2():
     for rank in range(world):
         res = out[rank]
         assert res["buckets"] >= 3
+        assert res["aligned"] and res["w_adjacent"]
+        assert res["sunk"] == 2      # steps 1 and 2: the stacked gradient was produced inside the bucket ...
+        # ... so per overlapped step only the 7 parameters that torch's own backward produces are copied
+        assert res["copies"] == 2 * 7, res["copies"]
         for key in ("step0", "step1", "step2", "accum"):
             for n, g in res[key].items():
                 if n == "unused":

@@ -2,8 +2,11 @@
 formula weights and inputs, and against the committed reference golden vectors.
 
 fp32 mode: tolerance 1e-5 on logits (BASELINE.json north_star), tight relative tolerances on
-gradients.  bf16 mode: 1e-3 target on logits is REPORTED (the reference's own bf16 autocast
-deviates 3.3e-3..7.2e-3 from its fp32); the asserted bound is 5e-3."""
+gradients.  bf16 mode: the small configs (micro / mini / tiny) are held to 1e-3 against the fp32 oracle.  At Base /
+Large size the rounding of the bf16 GEMM operands themselves moves the logits by 2.7e-3 (measured on the ORACLE:
+tools/bf16_budget.py, 98 % of it from rounding the weight operands), so there the HIP path is held to 1e-3 against
+the oracle that rounds the same operands to bf16 (`lowp=O.bf16_round`), and its distance to the fp32 oracle must not
+exceed that of the emulating oracle by more than 1e-3 (documented deviation)."""
 import glob
 import os
 
@@ -170,7 +173,7 @@ def test_bf16_fused_epilogues_match_unfused_and_oracle():
     e_or = (lf - logits_ref).abs().max().item()
     e_fu = (lf - lu).abs().max().item()
     print(f"[fused] max|dlogit| vs fp32 oracle {e_or:.3e}, fused vs unfused {e_fu:.3e}")
-    assert e_or < 5e-3 and e_fu < 2e-3
+    assert e_or < 1.5e-3 and e_fu < 1e-3
     for n in gf:
         a, b, r = gf[n].flatten().double(), gu[n].flatten().double(), p[n].grad.flatten().double()
         if r.norm() < 1e-12:
@@ -233,7 +236,7 @@ def test_kohonen_head_bf16_runs_and_tracks_oracle():
     eemu = (logits.cpu() - logits_emu).abs().max().item()
     print(f"[bf16 mini_k] max|dlogit| vs fp32 oracle {e32:.3e}, vs bf16-operand oracle {eemu:.3e}, "
           f"oracle fp32 vs bf16-operand {(logits_ref - logits_emu).abs().max().item():.3e}")
-    assert eemu < 1.5e-2 and e32 < 6e-2
+    assert eemu < 1e-3 and e32 < 2e-3
     assert abs(loss.item() - loss_ref.item()) < 2e-2 * abs(loss_ref.item())
     assert torch.isfinite(gnorm).item()
 
@@ -396,38 +399,119 @@ def test_kohonen_step_under_nan_poison():
     assert got == ref, (got, ref)
 
 
-def test_base_config_full_size_vs_cpu_oracle():
-    """BASELINE config C2 at full model size against the CPU oracle itself (B=2: a forward+backward of the fp32 oracle
-    takes a few seconds on the box's host cores): fp32 mode within the 1e-5 logits bar and 1e-3 on gradient norms; the
-    bf16 mode's distance to the same fp32 oracle is printed and bounded."""
-    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
-    cfg = named_config("base")
-    X, y = synthetic_batch(cfg, 2)
-    p, logits_ref, loss_ref, _ = oracle_run(cfg, X, y, True)
-    m = build(cfg, "fp32", True).train()
-    logits, aux = m(X.cuda())
-    loss = torch.nn.functional.cross_entropy(logits, y.cuda())
+def _oracle_with_taps(cfg, X, y, lowp):
+    p = O.make_params(formula_state_dict(cfg))
+    O.renorm_(p, cfg)
+    taps = {}
+    logits, aux = O.forward(p, cfg, X, lowp, taps=taps, training=True)
+    loss = O.cross_entropy(logits, y)
     loss.backward()
-    err = (logits.detach().cpu() - logits_ref).abs().max().item()
-    print(f"[base vs oracle] fp32 mode max|dlogit| {err:.3e} (|logit|max {logits_ref.abs().max().item():.3f}), "
-          f"loss {loss.item():.6f} vs {loss_ref:.6f}")
-    assert err < 1e-5
+    return p, logits.detach(), loss.detach(), {k: v.detach() for k, v in taps.items() if k.startswith("x")}
+
+
+def _hip_with_taps(m, X, y):
+    taps = {}
+    object.__setattr__(m, "_taps", taps)
+    try:
+        logits, aux = m(X.cuda())
+        loss = torch.nn.functional.cross_entropy(logits, y.cuda())
+        loss.backward()
+    finally:
+        object.__setattr__(m, "_taps", None)
+    B = X.shape[0]
+    return logits.detach().cpu(), loss.item(), {k: v.cpu().reshape(B, -1, v.shape[-1]) for k, v in taps.items()
+                                                if k.startswith("x")}
+
+
+def _layer_errors(taps, ref):
+    return [(taps[f"x{i}"] - ref[f"x{i}"]).abs().max().item() for i in range(len(ref))]
+
+
+def _full_size_bf16_parity(name, batch, grads: bool):
+    """Shared body of the Base / Large full-size tests.  Returns nothing; asserts and prints."""
+    from nvit_amd import _lib
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    cfg = named_config(name)
+    X, y = synthetic_batch(cfg, batch)
+    p32, l32, loss32, t32 = _oracle_with_taps(cfg, X, y, None)
+    pem, lem, lossem, tem = _oracle_with_taps(cfg, X, y, O.bf16_round)
+    lmax = l32.abs().max().item()
+    d_emu = (lem - l32).abs().max().item()
+    print(f"[{name} B={batch}] oracle: |logit|max {lmax:.3f}; bf16-operand oracle vs fp32 oracle {d_emu:.3e} "
+          f"(the intrinsic cost of bf16 MFMA operands at this size)")
+    # ---- fp32 mode: the 1e-5 bar, gradient norms to 1e-3
+    m = build(cfg, "fp32", True).train()
+    lg, loss, taps = _hip_with_taps(m, X, y)
+    e = (lg - l32).abs().max().item()
+    print(f"   fp32 mode : max|dlogit| {e:.3e}, loss {loss:.6f} vs {loss32:.6f}, residual stream per layer "
+          f"{max(_layer_errors(taps, t32)):.2e}")
+    assert e < 1e-5
     worst = 0.0
     for n, q in m.named_parameters():
-        if q.grad is None or p[n].grad is None:
+        if q.grad is None or p32[n].grad is None:
             continue
-        a, b = q.grad.cpu().double().norm().item(), p[n].grad.double().norm().item()
+        a, b = q.grad.cpu().double().norm().item(), p32[n].grad.double().norm().item()
         if b > 1e-9:
             worst = max(worst, abs(a / b - 1))
-    print(f"   worst relative gradient-norm error {worst:.3e}")
+    print(f"   fp32 mode : worst relative gradient-norm error {worst:.3e}")
     assert worst < 1e-3
     m.zero_grad(set_to_none=True)
+    # ---- bf16 mode, default kernel dispatch, then with the persistent kernels forced (the B=128 code path)
     m.set_precision("bf16")
-    with torch.no_grad():
-        lb, _ = m(X.cuda())
-    eb = (lb.cpu() - logits_ref).abs().max().item()
-    print(f"   bf16 mode max|dlogit| vs the fp32 oracle {eb:.3e}")
-    assert eb < 5e-3
+    results = {}
+    for tag, nt_impl in (("default dispatch", -1), ("persistent kernels forced", 2)):
+        _lib.load().nvit_set_gemm_impl(nt_impl if nt_impl >= 0 else 1, 1)
+        try:
+            m.zero_grad(set_to_none=True)
+            lb, lossb, tb = _hip_with_taps(m, X, y)
+        finally:
+            _lib.load().nvit_set_gemm_impl(1, 1)
+        e32, eem = (lb - l32).abs().max().item(), (lb - lem).abs().max().item()
+        le32, leem = _layer_errors(tb, t32), _layer_errors(tb, tem)
+        lo = _layer_errors(tem, t32)
+        print(f"   bf16 mode ({tag}): max|dlogit| vs bf16-operand oracle {eem:.3e}, vs fp32 oracle {e32:.3e} "
+              f"(rel {e32 / lmax:.2e})")
+        print("      residual stream max|dx| per layer  HIP-vs-emu : " + " ".join(f"{v:.1e}" for v in leem))
+        print("                                         HIP-vs-fp32: " + " ".join(f"{v:.1e}" for v in le32))
+        print("                                         emu-vs-fp32: " + " ".join(f"{v:.1e}" for v in lo))
+        results[tag] = (lb, e32, eem)
+        # the bar: within 1e-3 of the oracle that rounds the same GEMM operands to bf16 ...
+        assert eem < 1e-3, (tag, eem)
+        # ... and no further from the fp32 oracle than that emulation is, plus the same 1e-3
+        assert e32 < d_emu + 1e-3, (tag, e32, d_emu)
+        # no kernel term that grows with depth beyond what operand rounding explains: per layer, the HIP stream is
+        # at most as far from the emulation as the emulation is from fp32 (x2 slack), elementwise max over [B,T,C]
+        for i, (a, b) in enumerate(zip(leem, lo)):
+            assert a < 3.0 * b + 1e-4, (tag, i, a, b)
+        if grads:
+            worst_cos, worst_ratio = 1.0, 0.0
+            for n, q in m.named_parameters():
+                if q.grad is None or p32[n].grad is None:
+                    continue
+                a, b = q.grad.cpu().flatten().double(), p32[n].grad.flatten().double()
+                if b.norm() < 1e-12:
+                    continue
+                cos = (a @ b / (a.norm() * b.norm() + 1e-30)).item()
+                ratio = abs((a.norm() / b.norm()).item() - 1)
+                if a.numel() > 16:          # scalars (skip_param): cancellation-dominated, checked by ratio only
+                    worst_cos = min(worst_cos, cos)
+                    assert cos > 0.999, (tag, n, cos)
+                assert ratio < (0.02 if a.numel() > 16 else 0.25), (tag, n, ratio)
+                worst_ratio = max(worst_ratio, ratio if a.numel() > 16 else 0.0)
+            print(f"      gradients vs fp32 oracle: worst cosine {worst_cos:.6f}, worst norm ratio error {worst_ratio:.2e}")
+    a, b = results["default dispatch"][0], results["persistent kernels forced"][0]
+    print(f"   bf16 mode: default dispatch vs persistent kernels {(a - b).abs().max().item():.3e}")
+    assert (a - b).abs().max().item() < 1e-3
+    return m
+
+
+def test_base_config_full_size_vs_cpu_oracle():
+    """BASELINE config C2 at full model size against the CPU oracle, B=6 (M = 4704: the q/k-norm, SwiGLU and
+    SwiGLU-backward GEMM epilogues and the persistent weight-gradient kernel are all on the path; a second pass forces
+    the persistent NT kernels that B=128 uses).  fp32 mode: 1e-5 on logits, 1e-3 on gradient norms.  bf16 mode: 1e-3
+    against the bf16-operand oracle, gradients cosine >= 0.999 against the fp32 oracle, per-layer residual-stream
+    errors printed and bounded."""
+    _full_size_bf16_parity("base", 6, grads=True)
 
 
 def test_checkpoint_resume_is_exact(tmp_path):
@@ -462,25 +546,13 @@ def test_checkpoint_resume_is_exact(tmp_path):
 
 
 def test_large_config_full_size_vs_cpu_oracle():
-    """BASELINE config C4 (nViT-Large/16: C=1024, H=16, L=24) at full model size, one image, against the CPU oracle:
-    fp32 mode inside the 1e-5 logits bar, bf16 mode bounded; then one fused optimizer step keeps rows/columns unit."""
+    """BASELINE config C4 (nViT-Large/16: C=1024, H=16, L=24) at full model size, B=2, same bars as the Base test
+    (forward + per-layer stream + gradients); then one fused optimizer step keeps rows/columns unit."""
     from nvit_amd.train import train_step
-    torch.set_num_threads(max(1, min(16, len(__import__("os").sched_getaffinity(0)))))
+    m = _full_size_bf16_parity("large", 2, grads=True)
     cfg = named_config("large")
-    X, y = synthetic_batch(cfg, 1)
-    p, logits_ref, loss_ref, _ = oracle_run(cfg, X, y, True)
-    m = build(cfg, "fp32", True).train()
-    with torch.no_grad():
-        logits, _ = m(X.cuda())
-    err = (logits.cpu() - logits_ref).abs().max().item()
-    print(f"[large vs oracle] fp32 mode max|dlogit| {err:.3e} (|logit|max {logits_ref.abs().max().item():.3f})")
-    assert err < 1e-5
-    m.set_precision("bf16")
-    with torch.no_grad():
-        lb, _ = m(X.cuda())
-    eb = (lb.cpu() - logits_ref).abs().max().item()
-    print(f"   bf16 mode max|dlogit| vs the fp32 oracle {eb:.3e}")
-    assert eb < 8e-3
+    X, y = synthetic_batch(cfg, 2)
+    m.zero_grad(set_to_none=True)
     opt = m.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")
     _, loss, _, gnorm = train_step(m, opt, X.cuda(), y.cuda(), 1.0)
     assert torch.isfinite(loss).item() and torch.isfinite(gnorm).item()
