@@ -9,9 +9,15 @@ AdamW -> zero_grad -> weight re-normalisation, on one synthetic batch resident i
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line on rank 0 (see README/DESIGN for the fields).  The `roofline` object
-is for the dominant kernel family (the NT MFMA GEMM): algorithmic FLOPs of its launches over
-their HIP-event durations inside the timed region.  `cpu_baseline` times the CPU oracle
-(a port of the reference semantics, fp32) on this box's host cores on a bounded sample.
+is for the dominant kernel family (the plain-epilogue NT MFMA GEMM): algorithmic FLOPs of its
+launches over their HIP-event durations inside the timed region; `roofline.families` lists
+EVERY MFMA family of the step (plain NT, each fused epilogue, weight-gradient TN, attention
+forward / backward) with its own achieved TFLOP/s and fraction, so the weakest one is visible.
+The peak is derived from the device (CU count x 4096 bf16 FLOP/clk/CU x max clock), both printed.
+`cpu_baseline` times the CPU oracle (a port of the reference semantics, fp32) on this box's host
+cores as BASELINE.md §3 prescribes: C2 (Base) at B=8, 3 steps after one warm-up, and C1 (Tiny) at
+B=32, 10 steps.  `--check` runs the full-shape numeric check (tools/fullshape_check.py) and an
+end-to-end comparison after the timed region.
 """
 from __future__ import annotations
 
@@ -27,40 +33,103 @@ if ROOT not in sys.path:
 
 import torch
 
-PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz, dense (MI355X_MICROARCH.md)
+NOMINAL_PEAK_BF16_TFLOPS = 2516.6   # 256 CU x 4096 FLOP/clk/CU x 2.4 GHz, dense (MI355X_MICROARCH.md)
+BF16_FLOP_PER_CLK_PER_CU = 4096     # 4 SIMDs x (16x16x32 MFMA = 16384 FLOP per 16 cycles)
 PEAK_HBM_GBS = 8000.0
 
 
-def cpu_baseline(cfg_name: str, sample_batch: int, threads: int):
-    """Oracle (port of the reference's CPU fp32 semantics) timed on the host cores."""
+def device_peak(dev):
+    """(CU count, max clock in MHz, dense bf16 MFMA peak in TFLOP/s) from the device properties."""
+    prop = torch.cuda.get_device_properties(dev)
+    cus = int(prop.multi_processor_count)
+    mhz = float(getattr(prop, "clock_rate", 0)) / 1e3   # kHz -> MHz
+    if mhz <= 0:
+        mhz = 2400.0
+    return cus, mhz, cus * BF16_FLOP_PER_CLK_PER_CU * mhz * 1e6 / 1e12
+
+
+def _time_oracle_steps(cfg_name: str, batch: int, steps: int, warm: int, threads: int):
     from nvit_amd.config import named_config
-    from nvit_amd.weights import formula_state_dict, load_formula_weights, synthetic_batch
+    from nvit_amd.weights import formula_state_dict, synthetic_batch
     from oracle import nvit_oracle as O
     torch.set_num_threads(threads)
     cfg = named_config(cfg_name)
     p = O.make_params(formula_state_dict(cfg, perturb_scalars=False))
     O.renorm_(p, cfg)
     opt = O.make_optimizer(p)
-    X, y = synthetic_batch(cfg, sample_batch)
+    X, y = synthetic_batch(cfg, batch)
+    for _ in range(warm):
+        O.train_step(p, cfg, opt, X, y)
     t0 = time.time()
-    O.train_step(p, cfg, opt, X, y)
+    for i in range(steps):
+        O.train_step(p, cfg, opt, X, y)
+        print(f"[bench] cpu oracle {cfg_name} B={batch}: step {i + 1}/{steps} ({time.time() - t0:.1f} s)",
+              file=sys.stderr, flush=True)
     dt = time.time() - t0
-    return {"value": round(sample_batch / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"{cfg_name} (same workload), batch {sample_batch}, 1 full train step, fp32 torch-CPU oracle, "
-                      f"{dt:.1f} s"}
+    return batch * steps / dt, dt
+
+
+def cpu_baseline(cfg_name: str, sample_batch: int, threads: int):
+    """Oracle (port of the reference's CPU fp32 semantics) timed on the host cores, BASELINE.md §3: the benchmarked
+    config at B=8 for 3 steps after one warm-up step, and C1 (Tiny, the reference's own CPU-runnable case) at B=32
+    for 10 steps after one warm-up."""
+    ips, dt = _time_oracle_steps(cfg_name, sample_batch, 3, 1, threads)
+    out = {"value": round(ips, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+           "sample": f"{cfg_name} (same workload), batch {sample_batch}, 3 full train steps after 1 warm-up, fp32 "
+                     f"torch-CPU oracle, {dt:.1f} s"}
+    ips1, dt1 = _time_oracle_steps("tiny", 32, 10, 1, threads)
+    out["c1_tiny"] = {"value": round(ips1, 2), "unit": "images/sec",
+                      "sample": f"tiny (C1), batch 32, 10 full train steps after 1 warm-up, {dt1:.1f} s"}
+    return out
 
 
 def pmc_traffic():
-    """HBM-side bytes per gemm_nt launch from the committed rocprofv3 PMC summary of this same command
-    (profiles/*_pmc.json, made by tools/summarize_profile.py; PMC counters cannot be read inside the run)."""
+    """(HBM-side bytes per gemm_nt launch, the profile file they come from) from the committed rocprofv3 PMC summary
+    of this same command (profiles/*_pmc.json, made by tools/summarize_profile.py; PMC counters cannot be read inside
+    the run, so the source file is named in the JSON line and goes stale only visibly)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
     if not files:
-        return None
+        return None, None
     try:
-        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"])
+        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"]), os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, None
+
+
+def _gemm_nt_algorithmic_bytes(cfg, batch: int) -> float:
+    """Average algorithmic HBM bytes of one plain-epilogue gemm_nt launch of the Base-style step: per block o-proj
+    (K=C, fp32 out), mlp_c_proj (K=4C, fp32 out), c_fc dgrad (K=8C, fp32 accumulate: C read + written), qkv dgrad (K=3C,
+    accumulate), att_c_proj dgrad (K=C, bf16 out); A and B are bf16."""
+    C = cfg.n_embd
+    T = (cfg.image_size // cfg.local_patch_size) ** 2
+    M = batch * T
+    def one(K, out_bytes, acc):
+        return 2.0 * M * K + 2.0 * C * K + M * C * out_bytes * (2 if acc else 1)
+    launches = [one(C, 4, False), one(4 * C, 4, False), one(8 * C, 4, True), one(3 * C, 4, True), one(C, 2, False)]
+    return sum(launches) / len(launches)
+
+
+def run_check(model, cfg, args, X, dev):
+    """Correctness of the benchmarked shape itself, outside the timed region."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fullshape_check
+    T = (cfg.image_size // cfg.local_patch_size) ** 2
+    rep = fullshape_check.check_all(B=args.batch, T=T, C=cfg.n_embd, H=cfg.n_head, verbose=False, dev=dev)
+    bad = [k for k, v in rep.rows.items() if not v["ok"]]
+    # end to end: logits of the whole batch in the benchmarked mode vs the exact-f32 mode on the first 4 images
+    model.eval()
+    with torch.no_grad():
+        full, _ = model(X)
+        model.set_precision("fp32")
+        ref, _ = model(X[:4])
+        model.set_precision(args.precision)
+    model.train()
+    e2e = (full[:4] - ref).abs().max().item()
+    return {"kernels_checked": len(rep.rows), "failed": bad, "ok": not bad and e2e < 1e-2,
+            "worst_rel_to_tol": round(max(v["err"] / v["tol"] for v in rep.rows.values()), 3),
+            "e2e_logits_B%d_%s_vs_fp32mode_B4_max_abs" % (args.batch, args.precision): float(f"{e2e:.3e}"),
+            "e2e_logit_max_abs": round(ref.abs().max().item(), 3)}
 
 
 def main() -> None:
@@ -76,6 +145,9 @@ def main() -> None:
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: all ranks use cuda:0 (needs --backend gloo); not a valid benchmark")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--check", action="store_true",
+                    help="after the timed region: numeric check of every GEMM shape / epilogue and of attention at this "
+                         "batch size (tools/fullshape_check.py) and bf16 B=batch logits vs the exact-f32 mode")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one hipGraph (1 GPU, no Kohonen head); the per-kernel roofline is then "
                          "taken from a short eager pass after the timed region")
@@ -163,15 +235,66 @@ def main() -> None:
     if not torch.isfinite(loss).item():
         raise SystemExit("non-finite loss in the timed region")
 
+    # stand-alone nvit_renorm_weights (the kernel north_star singles out; the step itself uses the fused optimizer):
+    # 10 warm calls, outside the timed region
+    renorm_warm = None
+    if rank == 0:
+        for _ in range(3):
+            normalize_matrices(model)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            normalize_matrices(model)
+        e1.record()
+        torch.cuda.synchronize()
+        n_mat = sum(getattr(blk, n).weight.numel() for blk in model.transformer.h
+                    for n in ("query", "key", "value", "att_c_proj", "c_fc", "mlp_c_proj"))
+        t_ms = e0.elapsed_time(e1) / 10
+        renorm_warm = {"what": "stand-alone nvit_renorm_weights, 10 warm calls, 8 B/element (fp32 read + write)",
+                       "bytes": 8.0 * n_mat, "ms": round(t_ms, 4), "GB/s": round(8.0 * n_mat / (t_ms * 1e-3) / 1e9, 1),
+                       "frac_of_8TB/s": round(8.0 * n_mat / (t_ms * 1e-3) / 8e12, 3)}
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * args.batch * args.steps / dt
         gf = train_flops_per_image(cfg) / 1e9
+        cus, mhz, peak = device_peak(dev)
+        print(f"[bench] device: {torch.cuda.get_device_name(dev)}, {cus} CUs, max clock {mhz:.0f} MHz -> dense bf16 MFMA "
+              f"peak {peak:.1f} TFLOP/s (nominal {NOMINAL_PEAK_BF16_TFLOPS})", file=sys.stderr, flush=True)
+
+        def fam_of(key, label, executed_mult=1.0):
+            f = prof.get(key)
+            if not f or f["ms"] <= 0 or f["launches"] == 0:
+                return None
+            a = f["flops"] / (f["ms"] * 1e-3) / 1e12
+            d = {"kernel": label, "achieved": round(a, 1), "frac": round(a / peak, 4),
+                 "ms_per_step": round(f["ms"] / prof_steps, 3), "launches_per_step": round(f["launches"] / prof_steps, 1),
+                 "avg_launch_ms": round(f["ms"] / f["launches"], 4)}
+            if executed_mult != 1.0:
+                d["executed_incl_recompute"] = round(a * executed_mult, 1)
+            return d
+
         g = prof["gemm_nt"]            # plain-epilogue bf16 NT GEMMs: the dominant kernel of the step
         ach = g["flops"] / (g["ms"] * 1e-3) / 1e12 if g["ms"] > 0 else 0.0
-        gfu = prof.get("gemm_fused", {"flops": 0.0, "ms": 0.0})   # same kernel with SwiGLU / q-k-norm / SwiGLU-bwd epilogues
-        fam_ms = g["ms"] + gfu["ms"]
-        fam = (g["flops"] + gfu["flops"]) / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
+        fused_keys = ("gemm_swiglu", "gemm_qknorm", "gemm_swiglu_bwd")
+        fam_ms = g["ms"] + sum(prof[k]["ms"] for k in fused_keys)
+        fam_fl = g["flops"] + sum(prof[k]["flops"] for k in fused_keys)
+        fam = fam_fl / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
+        families = {
+            "gemm_nt_plain": fam_of("gemm_nt", "gemm_nt_persistent EPI 1/2 (bf16 / fp32 store)"),
+            "gemm_nt_swiglu": fam_of("gemm_swiglu", "gemm_nt_persistent EPI 3 (c_fc + suv + SwiGLU)"),
+            "gemm_nt_qknorm": fam_of("gemm_qknorm", "gemm_nt_persistent EPI 4 (qkv + per-head normalise + sqk)"),
+            "gemm_nt_swiglu_bwd": fam_of("gemm_swiglu_bwd", "gemm_nt_persistent EPI 5 (mlp_c_proj dgrad + SwiGLU backward)"),
+            "gemm_tn_wgrad": fam_of("gemm_tn", "gemm_tn_persistent + slab_reduce (weight gradients)"),
+            "attn_fwd": fam_of("attn_fwd", "attn_fwd_mfma (4*B*H*T^2*d)"),
+            # algorithmic backward = 10*B*H*T^2*d (five products); the two-kernel form executes 14 (S and dP twice)
+            "attn_bwd": fam_of("attn_bwd", "attn_bwd_dq_mfma + attn_bwd_dkv_mfma (10*B*H*T^2*d algorithmic)", 1.4),
+        }
+        families = {k: v for k, v in families.items() if v}
+        weakest = min(families, key=lambda k: families[k]["frac"]) if families else None
+        traffic, traffic_src = pmc_traffic()
+        # algorithmic bytes of an average plain gemm_nt launch: A [M,K] bf16 + B [N,K] bf16 + C [M,N] (4 B: fp32 outputs dominate)
         T = (cfg.image_size // cfg.local_patch_size) ** 2
         out = {
             "metric": "images/sec (train step) nViT-B/16 224px", "value": round(value, 2), "unit": "images/sec",
@@ -183,12 +306,15 @@ def main() -> None:
                                    f"full train step (fwd+bwd+clip+AdamW+renorm), synthetic images, formula weights",
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch,
                        "parallelism": f"dp{world}", "train_gflop_per_image": round(gf, 3)},
-            "step_mfma_frac": round(value * gf / 1e3 / (world * PEAK_BF16_TFLOPS), 4),
+            "step_mfma_frac": round(value * gf / 1e3 / (world * peak), 4),
+            "device": {"name": torch.cuda.get_device_name(dev), "compute_units": cus, "max_clock_mhz": round(mhz, 1),
+                       "peak_bf16_tflops_from_props": round(peak, 1), "nominal_peak_bf16_tflops": NOMINAL_PEAK_BF16_TFLOPS},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt (persistent 256x256 tile, bf16 v_mfma_f32_16x16x32, LDS-DMA ring)",
-                         "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(),
+                         "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(ach / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launches": g["launches"], "avg_launch_ms": round(g["ms"] / max(1, g["launches"]), 4),
-                         "family_achieved_incl_fused_epilogues": round(fam, 1)},
+                         "family_achieved_incl_fused_epilogues": round(fam, 1),
+                         "families": families, "weakest_family": weakest},
             "kernel_ms_per_step": {k: round(v["ms"] / prof_steps, 3) for k, v in prof.items() if v["launches"]},
         }
         # HBM-bound kernels of the path: algorithmic bytes (as declared at each launch) / HIP-event time, vs 8 TB/s
@@ -200,13 +326,22 @@ def main() -> None:
             if f and f["ms"] > 0 and f["bytes"] > 0:
                 hbm[fam] = {"what": label, "GB/s": round(f["bytes"] / (f["ms"] * 1e-3) / 1e9, 1),
                             "frac_of_8TB/s": round(f["bytes"] / (f["ms"] * 1e-3) / 8e12, 3)}
-        f = prof.get("renorm")
+        f = prof.get("optim")
         if f and f["ms"] > 0:
             by = 32.0 * n_upd * prof_steps   # p,g,m,v read + p,m,v written + g read again for the global norm
             hbm["optimizer+renorm"] = {"what": "clip + AdamW + normalize_matrices, 32 B/parameter",
                                        "GB/s": round(by / (f["ms"] * 1e-3) / 1e9, 1),
                                        "frac_of_8TB/s": round(by / (f["ms"] * 1e-3) / 8e12, 3)}
+        if renorm_warm:
+            hbm["renorm_standalone"] = renorm_warm
         out["hbm_kernels"] = hbm
+        if traffic:
+            # plain gemm_nt launches of the step: algorithmic bytes = A + B read once, C written once (per launch average)
+            alg = _gemm_nt_algorithmic_bytes(cfg, args.batch)
+            out["roofline"]["algorithmic_bytes"] = alg
+            out["roofline"]["traffic_over_algorithmic"] = round(traffic / alg, 3)
+        if args.check:
+            out["check"] = run_check(model, cfg, args, X, dev)
         if args.graph:
             out["graph"] = True
             out["roofline"]["source"] = f"{prof_steps} eager steps after the timed hipGraph replays"

@@ -46,8 +46,11 @@ const char* nvit_last_error(void);
 #define NVIT_KID_PATCHIFY 7
 #define NVIT_KID_MISC 8
 #define NVIT_KID_GEMM_F32 9 /* exact-f32 MFMA GEMMs (fp32 mode; patch embedding + classifier of the bf16 mode) */
-#define NVIT_KID_GEMM_FUSED 10 /* bf16 NT GEMMs with a fused epilogue: SwiGLU, q/k normalise, SwiGLU backward */
-#define NVIT_KID_COUNT 11
+#define NVIT_KID_GEMM_SWIGLU 10     /* bf16 NT GEMM with the SwiGLU epilogue (nvit_gemm_nt_swiglu) */
+#define NVIT_KID_GEMM_QKNORM 11     /* bf16 NT GEMM with the q/k-normalise + head-split epilogue (nvit_gemm_nt_qknorm) */
+#define NVIT_KID_GEMM_SWIGLU_BWD 12 /* bf16 NT GEMM with the SwiGLU-backward epilogue (nvit_gemm_nt_swiglu_bwd) */
+#define NVIT_KID_OPTIM 13           /* nvit_grad_sqnorm + nvit_adamw_renorm (NVIT_KID_RENORM = stand-alone nvit_renorm_weights) */
+#define NVIT_KID_COUNT 14
 void nvit_prof_enable(int on);
 /* Synchronises the recorded events and returns, per kernel family, total milliseconds,
  * algorithmic FLOPs, algorithmic bytes and launch count since the last collect. Host arrays
@@ -217,6 +220,11 @@ int nvit_scale_cols(const float* a, int lda, const float* s, float c, void* out,
  * impl: 0 = scalar-FMA reference kernel (any dt), 1 = MFMA flash kernel (bf16 only). */
 int nvit_attn_fwd(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, void* o, float* lse,
                   int B, int H, int Tq, int Tk, int d, void* stream);
+/* Same, for the nViT call sites where q and k are (sqk*c_q) * unit vectors per head (model.py:108-112): every score is
+ * bounded by max_d (sqk_d*c_q)^2, and while that bound is small (it is 1 at initialisation) the MFMA kernel takes
+ * probabilities relative to the bound instead of a running maximum (no per-tile max / rescale).  sqk: [H*d] fp32. */
+int nvit_attn_fwd_bounded(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, const float* sqk,
+                          float c_q, void* o, float* lse, int B, int H, int Tq, int Tk, int d, void* stream);
 /* delta [B,H,T] workspace fp32. dqh,dkh,dvh [B,H,T,d] type dt. */
 int nvit_attn_bwd(int dt, int impl, const void* dout, const void* qh, const void* kh, const void* vh, const void* o,
                   const float* lse, float scale, void* dqh, void* dkh, void* dvh, float* delta, int B, int H,

@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnvit_hip.so")
 
 F32, BF16, BF16X3 = 0, 1, 2
-KID_NAMES = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "rowops", "renorm", "shadow", "patchify", "misc", "gemm_f32", "gemm_fused"]
+KID_NAMES = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "rowops", "renorm", "shadow", "patchify", "misc", "gemm_f32",
+             "gemm_swiglu", "gemm_qknorm", "gemm_swiglu_bwd", "optim"]
 RENORM_ROWS_PER_ITEM = 16
 RENORM_COLS_PER_ITEM = 32
 
@@ -54,6 +55,7 @@ SIGNATURES = {
     "nvit_cast": [_vp, _vp, _i, _i64, _vp],
     "nvit_scale_cols": [_vp, _i, _vp, _f, _vp, _i, _i, _i, _i, _vp],
     "nvit_attn_fwd": [_i, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "nvit_attn_fwd_bounded": [_i, _i, _vp, _vp, _vp, _f, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_attn_bwd": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_attn_bwd_qknorm": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp, _vp,
                              _vp, _i, _i, _i, _i, _i, _vp],

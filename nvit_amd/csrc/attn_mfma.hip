@@ -115,6 +115,13 @@ __device__ __forceinline__ void tile_dma(const bf16* src, size_t ld, int row_bas
     glds16a(src + (size_t)row * ld + chunk * 8, tile_off + grp * 1024);
   }
 }
+// Make the compiler retire its own pending global loads of `v` HERE (it inserts the s_waitcnt in front of this empty
+// statement).  Without it the wait lands at the first use INSIDE the tile loop, where - hipcc does not see the
+// LDS-DMA issued by inline asm - its vmcnt(0) also drains the K/V tiles that were just requested two tiles ahead,
+// i.e. every tile pays a full memory round trip (cdna_hip_programming.md, "mixing load KINDS in one k-loop").
+__device__ __forceinline__ void settle(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void settle(float& v) { asm volatile("" : "+v"(v)); }
+
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)p);
 }
@@ -132,8 +139,19 @@ __device__ __forceinline__ void work_of(int ntile, int& bh, int& tile) {
 }
 
 // ------------------------------------------------------------------------------------------ forward
+// `sqk` != NULL (nViT call sites): q and k are s * unit vectors with s = sqk*c_q per channel, so every score obeys
+// |q.k| <= smax^2 (smax = max_d |s_d| of the head).  When that bound is small enough that exp2 cannot underflow
+// (BOUND_MAX), the kernel takes the FAST path: probabilities are taken relative to the bound instead of a running
+// maximum - no per-tile max, no correction factor, no rescale of the output accumulators (about half of the
+// VALU work of a tile at head dim 64, where this kernel is VALU-issue bound, not MFMA bound) - and the row sums come
+// out of the MFMA pipe as one extra "ones" row of the V^T operand.  Softmax is shift invariant, so the result is the
+// same function; lse = ln(sum) + bound.  Otherwise (generic q/k, or a learned scale beyond the limit) the online
+// softmax below runs.
+constexpr float BOUND_MAX = 60.0f;   // in log2 units: exp2(-2*60) is still a normal fp32 / bf16 number
+
 __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __restrict__ qh, const bf16* __restrict__ kh,
                                                              const bf16* __restrict__ vh, float scale,
+                                                             const float* __restrict__ sqk, float c_q,
                                                              bf16* __restrict__ o, float* __restrict__ lse, int H,
                                                              int Tq, int Tk) {
   __shared__ __attribute__((aligned(16))) char lds[3][2][TILE_BYTES];  // ring [slot][K|V]
@@ -148,20 +166,23 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
   const float c2 = scale * LOG2E;
 
   uint4 qf[2][2];
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    int q = q0 + 16 * f + l15;
-    q = q < Tq ? q : Tq - 1;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-      qf[f][ks] = *reinterpret_cast<const uint4*>(qh + ((size_t)bh * Tq + q) * D + ks * 32 + lg * 8);
-  }
   f32x4 oacc[4][2];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int f = 0; f < 2; ++f) oacc[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m_[2] = {-INFINITY, -INFINITY}, l_[2] = {0.f, 0.f};
+  // score bound of this head in log2 units (fast path) - wave-uniform
+  float tb = INFINITY;
+  if (sqk) {
+    float sm = fabsf(sqk[h * D + lane] * c_q);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sm = fmaxf(sm, __shfl_xor(sm, off, 64));
+    tb = c2 * sm * sm;
+  }
+  const bool fast = __builtin_amdgcn_readfirstlane(tb <= BOUND_MAX ? 1 : 0) != 0;
+  f32x4 lacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};   // fast path: row sums from the MFMA pipe
+  const uint4 ones = make_uint4(0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u);   // 8 x bf16 1.0
 
   const int nt = (Tk + TKV - 1) / TKV;
   // K/V ring: LDS-DMA two tiles ahead, counted vmcnt (4 younger DMA instructions may stay in flight)
@@ -171,24 +192,84 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
   if (nt > 1) {
     tile_dma(kbase, D, TKV, Tk, ring + 2 * TILE_BYTES, lane, wid);
     tile_dma(vbase, D, TKV, Tk, ring + 3 * TILE_BYTES, lane, wid);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  // the wave's own Q rows: requested AFTER the DMA (one memory round trip for everything) and settled before the loop
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    int q = q0 + 16 * f + l15;
+    q = q < Tq ? q : Tq - 1;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      qf[f][ks] = *reinterpret_cast<const uint4*>(qh + ((size_t)bh * Tq + q) * D + ks * 32 + lg * 8);
+  }
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) settle(qf[f][ks]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler's own wait above already drained the queue)
   __syncthreads();
   int cur = 0;
   // Ragged sequence lengths (T = 784 = 6.125 x 128 = 12.25 x 64): a wave whose 32 queries all lie past Tq only feeds the
   // K/V ring and the barriers (wave_active), and the ragged last KV tile - peeled, so the steady-state tiles spend no
   // VALU on masks - multiplies and exponentiates only its valid 16-key fragments (nkf) / 32-key MFMA steps (ns2).
   const bool wave_active = q0 < Tq;
-  auto tile_body = [&](const int t, auto masked_) {
+  auto tile_body = [&](const int t, auto masked_, auto fast_) {
     constexpr bool MASKED = decltype(masked_)::value;
+    constexpr bool FAST = decltype(fast_)::value;
     if (t + 2 < nt) {
       const int sl = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
       tile_dma(kbase, D, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid);
       tile_dma(vbase, D, (t + 2) * TKV, Tk, ring + (2 * sl + 1) * TILE_BYTES, lane, wid);
     }
-    if (wave_active) {
+    if (wave_active && FAST) {
+      const char* kt = &lds[cur][0][0];
+      const char* vt = &lds[cur][1][0];
+      const int nvalid = MASKED ? Tk - t * TKV : TKV;
+      const int nkf = MASKED ? (nvalid + 15) >> 4 : 4, ns2 = MASKED ? (nvalid + 31) >> 5 : 2;
+      uint4 pf[2][2];  // [s2][f]
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f32x4 p_[2][2];   // [kk][f], key fragment kf = 2*s2 + kk
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int kf = 2 * s2 + kk;
+          if (!MASKED || kf < nkf) {
+            const uint4 a0 = row_frag(kt, kf * 16, 0, l15, lg), a1 = row_frag(kt, kf * 16, 1, l15, lg);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+              f32x4 z = {0.f, 0.f, 0.f, 0.f};
+              z = mfma16(a0, qf[f][0], z);
+              z = mfma16(a1, qf[f][1], z);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float p = fast_exp2(z[r] * c2 - tb);
+                if (MASKED && kf * 16 + lg * 4 + r >= nvalid) p = 0.f;
+                p_[kk][f][r] = p;
+              }
+            }
+          } else {
+            p_[kk][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            p_[kk][1] = p_[kk][0];
+          }
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) pf[s2][f] = pack8(p_[0][f], p_[1][f]);
+      }
+      // O^T[df][f] += V^T P^T, and the row sums l[f] += 1^T P^T
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        if (!MASKED || s2 < ns2) {
+#pragma unroll
+          for (int f = 0; f < 2; ++f) lacc[f] = mfma16(ones, pf[s2][f], lacc[f]);
+#pragma unroll
+          for (int df = 0; df < 4; ++df) {
+            const uint4 va = tr_frag(vt, s2 * 32, df * 16, l15, lg);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) oacc[df][f] = mfma16(va, pf[s2][f], oacc[df][f]);
+          }
+        }
+    }
+    if (wave_active && !FAST) {
       const char* kt = &lds[cur][0][0];
       const char* vt = &lds[cur][1][0];
       const int kbase_i = t * TKV;
@@ -270,23 +351,38 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
     __syncthreads();
     cur = cur == 2 ? 0 : cur + 1;
   };
-  for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{});
-  if (Tk % TKV)
-    tile_body(nt - 1, std::true_type{});
-  else
-    tile_body(nt - 1, std::false_type{});
+  if (fast) {
+    for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{}, std::true_type{});
+    if (Tk % TKV)
+      tile_body(nt - 1, std::true_type{}, std::true_type{});
+    else
+      tile_body(nt - 1, std::false_type{}, std::true_type{});
+  } else {
+    for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{}, std::false_type{});
+    if (Tk % TKV)
+      tile_body(nt - 1, std::true_type{}, std::false_type{});
+    else
+      tile_body(nt - 1, std::false_type{}, std::false_type{});
+  }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
-    float l = l_[f];
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    float l, lse_v;
+    if (fast) {
+      l = lacc[f][0];   // every row of the ones-operand product is the full sum over the keys
+      lse_v = (tb + log2f(l)) * (1.0f / LOG2E);
+    } else {
+      l = l_[f];
+      l += __shfl_xor(l, 16, 64);
+      l += __shfl_xor(l, 32, 64);
+      lse_v = m_[f] * scale + logf(l);
+    }
     const int q = q0 + 16 * f + l15;
     if (q < Tq) {
       const float inv = 1.0f / l;
       bf16* op = o + ((size_t)b * Tq + q) * (H * D) + h * D + 4 * lg;
 #pragma unroll
       for (int df = 0; df < 4; ++df) store4<bf16>(op + df * 16, oacc[df][f] * inv);
-      if (lg == 0) lse[(size_t)bh * Tq + q] = m_[f] * scale + logf(l);
+      if (lg == 0) lse[(size_t)bh * Tq + q] = lse_v;
     }
   }
 }
@@ -383,6 +479,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
 
   uint4 qf[2][2], gf[2][2];
   float lse2[2], dl[2];
+  const int nt = (Tk + TKV - 1) / TKV;
+  // K/V ring: LDS-DMA two tiles ahead, counted vmcnt (4 younger DMA instructions may stay in flight); the prologue
+  // DMA goes out first, the wave's own rows after it, and everything is settled before the tile loop (see settle())
+  const unsigned ring = lds_addr(&lds[0][0][0]);
+  tile_dma(kbase, D, 0, Tk, ring, lane, wid);
+  tile_dma(vbase, D, 0, Tk, ring + TILE_BYTES, lane, wid);
+  if (nt > 1) {
+    tile_dma(kbase, D, TKV, Tk, ring + 2 * TILE_BYTES, lane, wid);
+    tile_dma(vbase, D, TKV, Tk, ring + 3 * TILE_BYTES, lane, wid);
+  }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const int qu = q0 + 16 * f + l15;
@@ -415,20 +521,25 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int f = 0; f < 2; ++f) dq[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nt = (Tk + TKV - 1) / TKV;
-  // K/V ring: LDS-DMA two tiles ahead, counted vmcnt (4 younger DMA instructions may stay in flight)
-  const unsigned ring = lds_addr(&lds[0][0][0]);
-  tile_dma(kbase, D, 0, Tk, ring, lane, wid);
-  tile_dma(vbase, D, 0, Tk, ring + TILE_BYTES, lane, wid);
-  if (nt > 1) {
-    tile_dma(kbase, D, TKV, Tk, ring + 2 * TILE_BYTES, lane, wid);
-    tile_dma(vbase, D, TKV, Tk, ring + 3 * TILE_BYTES, lane, wid);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    settle(lse2[f]);
+    settle(dl[f]);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      settle(qf[f][ks]);
+      settle(gf[f][ks]);
+    }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // -delta as the initial accumulator of the dP product: loop-invariant register quads (passed as the MFMA's C operand)
+  f32x4 ndl[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    ndl[f] = (f32x4){-dl[f], -dl[f], -dl[f], -dl[f]};
+    asm volatile("" : "+v"(ndl[f]));
+  }
   int cur = 0;
   const bool wave_active = q0 < Tq;   // see the forward kernel
   auto tile_body = [&](const int t, auto masked_) {
@@ -460,14 +571,13 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
                 f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 z = mfma16(a0, qf[f][0], z);
                 z = mfma16(a1, qf[f][1], z);  // S^T
-                f32x4 w = {0.f, 0.f, 0.f, 0.f};
-                w = mfma16(v0, gf[f][0], w);
-                w = mfma16(v1, gf[f][1], w);  // dP^T
+                f32x4 w = mfma16(v0, gf[f][0], ndl[f]);        // row constant -delta as the initial accumulator
+                w = mfma16(v1, gf[f][1], w);  // dP^T - delta
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const bool valid = !MASKED || (kf * 16 + lg * 4 + r) < nvalid;
                   const float p = valid ? fast_exp2(z[r] * c2 - lse2[f]) : 0.f;
-                  ds_[kk][f][r] = p * (w[r] - dl[f]) * scale;
+                  ds_[kk][f][r] = p * w[r];   // the softmax scale is applied once, to the dQ accumulators
                 }
               }
             } else {
@@ -502,6 +612,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
     tile_body(nt - 1, std::true_type{});
   else
     tile_body(nt - 1, std::false_type{});
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) dq[i][f] = dq[i][f] * scale;
   if constexpr (FUSE) {
     qk_bwd_epilogue(dq, qh + (size_t)bh * Tq * D, fu, q0, Tq, H, b, h, lane, wid, reinterpret_cast<float*>(&lds[0][0][0]),
                     tile_, (Tq + 127) / 128);
@@ -519,16 +633,43 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
 }
 
 // ------------------------------------------------------------------------------------------ dK, dV
+// 4-byte-per-lane LDS-DMA (one wave-instruction = 64 consecutive floats): the per-query lse / delta of a tile
+__device__ __forceinline__ void glds4a(const void* gsrc, unsigned lds_off) {
+  unsigned keep;
+  const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_off);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(m)
+      : "memory");
+}
+__device__ __forceinline__ uint2 pack4(const f32x4& a) {
+  bf16x4 v = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3]};
+  return __builtin_bit_cast(uint2, v);
+}
+
+// One workgroup = 4 waves x 32 keys; the 64-query tiles of Q and dO (+ their lse / delta rows) arrive by LDS-DMA into a
+// 3-slot ring two tiles ahead (counted vmcnt, one barrier per tile) - the same machine as the forward / dq kernels,
+// instead of the register-staged double buffer this kernel used before (which spilled at 3 waves per SIMD).
+// -delta enters as the initial accumulator of the dP product, the softmax scale is applied once to the dK accumulators,
+// and P / dS are packed to bf16 as soon as a 16-query fragment is done, so only packed halves stay live.
+constexpr int DKV_SLOT = 2 * TILE_BYTES + 512;     // Q tile | dO tile | lse[64] | delta[64]
+constexpr int DKV_DMA = 2 * TILE_DMA + 2;          // DMA wave-instructions per wave per tile
+#ifndef NVIT_DKV_WAVES
+#define NVIT_DKV_WAVES 2
+#endif
+constexpr int DKV_WAVES = NVIT_DKV_WAVES;          // waves per SIMD the register budget is sized for
+
 template <bool FUSE>
-__global__ __launch_bounds__(256, 3) void attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
+__global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
                                                                  const bf16* __restrict__ kh, const bf16* __restrict__ vh,
                                                                  const float* __restrict__ lse,
                                                                  const float* __restrict__ delta, float scale,
                                                                  bf16* __restrict__ dkh, bf16* __restrict__ dvh, int H,
                                                                  int Tq, int Tk, QkFuse fu) {
-  __shared__ __attribute__((aligned(16))) char lds[2][2][TILE_BYTES];  // [buf][Q|dO]
-  __shared__ __attribute__((aligned(16))) float stat[2][2][TKV];       // [buf][lse2|delta]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  __shared__ __attribute__((aligned(16))) char lds[3 * DKV_SLOT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
   int bh, tile_;
   work_of((Tk + 127) / 128, bh, tile_);
@@ -536,7 +677,23 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_mfma_kernel(const bf16* _
   const int k0 = tile_ * 128 + wid * 32;
   const bf16* qbase = qh + (size_t)bh * Tq * D;
   const bf16* gbase = dout + (size_t)b * Tq * (H * D) + h * D;
+  const float* lbase = lse + (size_t)bh * Tq;
+  const float* dbase = delta + (size_t)bh * Tq;
   const float c2 = scale * LOG2E;
+  const int nt = (Tq + TKV - 1) / TKV;
+  const unsigned ring = lds_addr(&lds[0]);
+
+  auto tile_issue = [&](int t, int slot) {
+    const unsigned so = ring + (unsigned)slot * DKV_SLOT;
+    tile_dma(qbase, D, t * TKV, Tq, so, lane, wid);
+    tile_dma(gbase, (size_t)H * D, t * TKV, Tq, so + TILE_BYTES, lane, wid);
+    int q = t * TKV + lane;
+    q = q < Tq ? q : Tq - 1;
+    glds4a(lbase + q, so + 2 * TILE_BYTES);        // every wave writes the same 256 bytes (keeps vmcnt uniform)
+    glds4a(dbase + q, so + 2 * TILE_BYTES + 256);
+  };
+  tile_issue(0, 0);
+  if (nt > 1) tile_issue(1, 1);
 
   uint4 kf_[2][2], vf_[2][2];  // [key frag][ks]: K / V rows of this wave's 32 keys (MFMA-B operands)
 #pragma unroll
@@ -549,6 +706,16 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_mfma_kernel(const bf16* _
       vf_[f][ks] = *reinterpret_cast<const uint4*>(vh + ((size_t)bh * Tk + k) * D + ks * 32 + lg * 8);
     }
   }
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      settle(kf_[f][ks]);
+      settle(vf_[f][ks]);
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
   f32x4 dk[4][2], dv[4][2];  // [df][key frag]: rows d = 16df + 4lg + r, col key = l15
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -557,90 +724,86 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_mfma_kernel(const bf16* _
       dk[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
       dv[i][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-
-  const int nt = (Tq + TKV - 1) / TKV;
-  Stage2 sq, sg;
-  float st_l = 0.f, st_d = 0.f;
-  auto stat_load = [&](int tq0) {
-    if (tid < TKV) {
-      const int q = tq0 + tid;
-      const bool ok = q < Tq;
-      st_l = ok ? lse[(size_t)bh * Tq + q] * LOG2E : INFINITY;  // exp2(x - inf) = 0 for padded queries
-      st_d = ok ? delta[(size_t)bh * Tq + q] : 0.f;
-    }
-  };
-  stage_load(sq, qbase, D, 0, Tq, tid);
-  stage_load(sg, gbase, (size_t)H * D, 0, Tq, tid);
-  stat_load(0);
-  stage_store(sq, &lds[0][0][0], tid);
-  stage_store(sg, &lds[0][1][0], tid);
-  if (tid < TKV) {
-    stat[0][0][tid] = st_l;
-    stat[0][1][tid] = st_d;
-  }
-  __syncthreads();
+  const bool wave_active = k0 < Tk;   // a wave whose 32 keys all lie past Tk only feeds the ring and the barriers
   int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    {
-      const int tn = (t + 1 < nt) ? t + 1 : t;
-      stage_load(sq, qbase, D, tn * TKV, Tq, tid);
-      stage_load(sg, gbase, (size_t)H * D, tn * TKV, Tq, tid);
-      stat_load(tn * TKV);
-    }
-    const char* qt = &lds[cur][0][0];
-    const char* gt = &lds[cur][1][0];
+  auto tile_body = [&](const int t, auto masked_) {
+    constexpr bool MASKED = decltype(masked_)::value;
+    if (t + 2 < nt) tile_issue(t + 2, cur == 0 ? 2 : cur - 1);
+    if (wave_active) {
+      const char* qt = &lds[cur * DKV_SLOT];
+      const char* gt = qt + TILE_BYTES;
+      const float* st = reinterpret_cast<const float*>(qt + 2 * TILE_BYTES);
+      const int nvalid = MASKED ? Tq - t * TKV : TKV;   // queries of this tile that exist
+      const int nqf = MASKED ? (nvalid + 15) >> 4 : 4, ns2 = MASKED ? (nvalid + 31) >> 5 : 2;
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      f32x4 p_[2][2], ds_[2][2];  // [qq][key frag]; query frag qfi = 2*s2 + qq, rows q = 16qfi + 4lg + r
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (MASKED && s2 >= ns2) continue;
+        uint2 ph[2][2], sh[2][2];  // [qq][key frag] packed bf16 P / dS of query frag qfi = 2*s2 + qq (rows 16qfi + 4lg + r)
 #pragma unroll
-      for (int qq = 0; qq < 2; ++qq) {
-        const int qfi = 2 * s2 + qq;
-        const uint4 a0 = row_frag(qt, qfi * 16, 0, l15, lg), a1 = row_frag(qt, qfi * 16, 1, l15, lg);
-        const uint4 g0 = row_frag(gt, qfi * 16, 0, l15, lg), g1 = row_frag(gt, qfi * 16, 1, l15, lg);
-        const f32x4 l4 = *reinterpret_cast<const f32x4*>(&stat[cur][0][qfi * 16 + 4 * lg]);
-        const f32x4 d4 = *reinterpret_cast<const f32x4*>(&stat[cur][1][qfi * 16 + 4 * lg]);
+        for (int qq = 0; qq < 2; ++qq) {
+          const int qfi = 2 * s2 + qq;
+          if (!MASKED || qfi < nqf) {
+            const uint4 a0 = row_frag(qt, qfi * 16, 0, l15, lg), a1 = row_frag(qt, qfi * 16, 1, l15, lg);
+            const uint4 g0 = row_frag(gt, qfi * 16, 0, l15, lg), g1 = row_frag(gt, qfi * 16, 1, l15, lg);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(st + qfi * 16 + 4 * lg) * LOG2E;
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(st + 64 + qfi * 16 + 4 * lg);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+              f32x4 z = {0.f, 0.f, 0.f, 0.f};
+              z = mfma16(a0, kf_[f][0], z);
+              z = mfma16(a1, kf_[f][1], z);  // S[q][key]
+              f32x4 w = -d4;                 // row constants as the initial accumulator
+              w = mfma16(g0, vf_[f][0], w);
+              w = mfma16(g1, vf_[f][1], w);  // dP[q][key] - delta[q]
+              f32x4 p, dsv;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float pr = fast_exp2(z[r] * c2 - l4[r]);
+                if (MASKED && qfi * 16 + lg * 4 + r >= nvalid) pr = 0.f;
+                p[r] = pr;
+                dsv[r] = pr * w[r];
+              }
+              ph[qq][f] = pack4(p);
+              sh[qq][f] = pack4(dsv);
+            }
+          } else {
+            ph[qq][0] = ph[qq][1] = sh[qq][0] = sh[qq][1] = make_uint2(0u, 0u);
+          }
+        }
+        uint4 pb[2], sb[2];
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
-          f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          z = mfma16(a0, kf_[f][0], z);
-          z = mfma16(a1, kf_[f][1], z);  // S[q][key]
-          f32x4 w = {0.f, 0.f, 0.f, 0.f};
-          w = mfma16(g0, vf_[f][0], w);
-          w = mfma16(g1, vf_[f][1], w);  // dP[q][key]
+          pb[f] = make_uint4(ph[0][f].x, ph[0][f].y, ph[1][f].x, ph[1][f].y);
+          sb[f] = make_uint4(sh[0][f].x, sh[0][f].y, sh[1][f].x, sh[1][f].y);
+        }
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = fast_exp2(z[r] * c2 - l4[r]);
-            p_[qq][f][r] = p;
-            ds_[qq][f][r] = p * (w[r] - d4[r]) * scale;
+        for (int df = 0; df < 4; ++df) {
+          const uint4 ga = tr_frag(gt, s2 * 32, df * 16, l15, lg);  // dO^T[d][q slots]
+          const uint4 qa = tr_frag(qt, s2 * 32, df * 16, l15, lg);  // Q^T[d][q slots]
+#pragma unroll
+          for (int f = 0; f < 2; ++f) {
+            dv[df][f] = mfma16(ga, pb[f], dv[df][f]);
+            dk[df][f] = mfma16(qa, sb[f], dk[df][f]);
           }
         }
       }
-      uint4 pb[2], sb[2];
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        pb[f] = pack8(p_[0][f], p_[1][f]);
-        sb[f] = pack8(ds_[0][f], ds_[1][f]);
-      }
-#pragma unroll
-      for (int df = 0; df < 4; ++df) {
-        const uint4 ga = tr_frag(gt, s2 * 32, df * 16, l15, lg);  // dO^T[d][q slots]
-        const uint4 qa = tr_frag(qt, s2 * 32, df * 16, l15, lg);  // Q^T[d][q slots]
-#pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          dv[df][f] = mfma16(ga, pb[f], dv[df][f]);
-          dk[df][f] = mfma16(qa, sb[f], dk[df][f]);
-        }
-      }
     }
-    stage_store(sq, &lds[cur ^ 1][0][0], tid);
-    stage_store(sg, &lds[cur ^ 1][1][0], tid);
-    if (tid < TKV) {
-      stat[cur ^ 1][0][tid] = st_l;
-      stat[cur ^ 1][1][tid] = st_d;
-    }
+    if (t + 2 < nt)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DKV_DMA) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
-  }
+    cur = cur == 2 ? 0 : cur + 1;
+  };
+  for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{});
+  if (Tq % TKV)
+    tile_body(nt - 1, std::true_type{});
+  else
+    tile_body(nt - 1, std::false_type{});
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) dk[i][f] = dk[i][f] * scale;
   if constexpr (FUSE) {
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -651,7 +814,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_mfma_kernel(const bf16* _
         for (int df = 0; df < 4; ++df) store4<bf16>(vp + df * 16, dv[df][f]);
       }
     }
-    qk_bwd_epilogue(dk, kh + (size_t)bh * Tk * D, fu, k0, Tk, H, b, h, lane, wid, reinterpret_cast<float*>(&lds[0][0][0]),
+    qk_bwd_epilogue(dk, kh + (size_t)bh * Tk * D, fu, k0, Tk, H, b, h, lane, wid, reinterpret_cast<float*>(&lds[0]),
                     tile_, (Tk + 127) / 128);
   } else {
 #pragma unroll
@@ -672,12 +835,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkv_mfma_kernel(const bf16* _
 
 }  // namespace
 
-int nvit_attn_fwd_mfma(const void* qh, const void* kh, const void* vh, float scale, void* o, float* lse, int B, int H,
-                       int Tq, int Tk, int d, hipStream_t s) {
+int nvit_attn_fwd_mfma(const void* qh, const void* kh, const void* vh, float scale, const float* sqk, float c_q, void* o,
+                       float* lse, int B, int H, int Tq, int Tk, int d, hipStream_t s) {
   NVIT_REQUIRE(d == 64, "attn_fwd: the MFMA kernel supports head dim 64 only (got %d)", d);
   dim3 grid((unsigned)(cdiv(Tq, 128) * B * H));
   hipLaunchKernelGGL(attn_fwd_mfma_kernel, grid, dim3(256), 0, s, (const bf16*)qh, (const bf16*)kh, (const bf16*)vh,
-                     scale, (bf16*)o, lse, H, Tq, Tk);
+                     scale, sqk, c_q, (bf16*)o, lse, H, Tq, Tk);
   NVIT_CHECK_LAUNCH("attn_fwd_mfma");
   return NVIT_OK;
 }

@@ -191,8 +191,8 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_ref(const T* dout, const T* q
 
 }  // namespace
 
-int nvit_attn_fwd_mfma(const void* qh, const void* kh, const void* vh, float scale, void* o, float* lse, int B, int H,
-                       int Tq, int Tk, int d, hipStream_t s);
+int nvit_attn_fwd_mfma(const void* qh, const void* kh, const void* vh, float scale, const float* sqk, float c_q, void* o,
+                       float* lse, int B, int H, int Tq, int Tk, int d, hipStream_t s);
 int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const void* vh, const void* o, const float* lse,
                        float* delta, float scale, void* dqh, void* dkh, void* dvh, int B, int H, int Tq, int Tk,
                        int d, hipStream_t s);
@@ -202,15 +202,32 @@ int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, c
                              float c_q, void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q, float* part_k, int B,
                              int H, int Tq, int Tk, int d, hipStream_t s);
 
+static int attn_fwd_impl(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, const float* sqk,
+                         float c_q, void* o, float* lse, int B, int H, int Tq, int Tk, int d, void* stream);
+
 extern "C" int nvit_attn_fwd(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, void* o,
                              float* lse, int B, int H, int Tq, int Tk, int d, void* stream) {
+  return attn_fwd_impl(dt, impl, qh, kh, vh, scale, nullptr, 0.f, o, lse, B, H, Tq, Tk, d, stream);
+}
+
+// nViT call sites: q and k are (sqk*c_q) * unit vectors per head, which bounds every score; the MFMA kernel then skips
+// the running maximum (see attn_mfma.hip).  Same result as nvit_attn_fwd up to rounding.
+extern "C" int nvit_attn_fwd_bounded(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale,
+                                     const float* sqk, float c_q, void* o, float* lse, int B, int H, int Tq, int Tk, int d,
+                                     void* stream) {
+  NVIT_REQUIRE(sqk != nullptr, "attn_fwd_bounded: sqk is NULL (use nvit_attn_fwd)");
+  return attn_fwd_impl(dt, impl, qh, kh, vh, scale, sqk, c_q, o, lse, B, H, Tq, Tk, d, stream);
+}
+
+static int attn_fwd_impl(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, const float* sqk,
+                         float c_q, void* o, float* lse, int B, int H, int Tq, int Tk, int d, void* stream) {
   NVIT_REQUIRE(d == 32 || d == 64, "attn_fwd: head dim %d unsupported (32 or 64)", d);
   NVIT_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "attn_fwd: empty problem");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(NVIT_KID_ATTN_FWD, 4.0 * B * H * (double)Tq * Tk * d, 0.0, s);
   if (impl == 1) {
     NVIT_REQUIRE(dt == NVIT_BF16, "attn_fwd: MFMA kernel needs bf16");
-    return nvit_attn_fwd_mfma(qh, kh, vh, scale, o, lse, B, H, Tq, Tk, d, s);
+    return nvit_attn_fwd_mfma(qh, kh, vh, scale, sqk, c_q, o, lse, B, H, Tq, Tk, d, s);
   }
   dim3 grid(cdiv(Tq, 64), B * H);
 #define L(T, D) \

@@ -103,6 +103,7 @@ extern "C" int nvit_prof_collect(double* ms, double* flops, double* bytes, int64
 
 extern "C" const char* nvit_prof_name(int kid) {
   static const char* names[NVIT_KID_COUNT] = {"gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "rowops",
-                                              "renorm",  "shadow",  "patchify", "misc",     "gemm_f32", "gemm_fused"};
+                                              "renorm",  "shadow",  "patchify", "misc",     "gemm_f32", "gemm_swiglu",
+                                              "gemm_qknorm", "gemm_swiglu_bwd", "optim"};
   return (kid >= 0 && kid < NVIT_KID_COUNT) ? names[kid] : "?";
 }

@@ -529,7 +529,7 @@ extern "C" int nvit_gemm_nt_swiglu(int dt, const void* A, int lda, const void* B
   g.gs = gs;
   g.gscale = gscale;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_GEMM_FUSED, 2.0 * M * (2.0 * F) * K, 0.0, s);
+  ProfScope ps(NVIT_KID_GEMM_SWIGLU, 2.0 * M * (2.0 * F) * K, 0.0, s);
   return nvit_gemm_nt_fused_launch(g, 3, s);
 }
 
@@ -560,7 +560,7 @@ extern "C" int nvit_gemm_nt_swiglu_bwd(int dt, const void* A, int lda, const voi
   g.gscale = gscale;
   g.part = gs ? part : nullptr;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_GEMM_FUSED, 2.0 * M * (double)F * K, 0.0, s);
+  ProfScope ps(NVIT_KID_GEMM_SWIGLU_BWD, 2.0 * M * (double)F * K, 0.0, s);
   return nvit_gemm_nt_fused_launch(g, 5, s);
 }
 
@@ -596,6 +596,6 @@ extern "C" int nvit_gemm_nt_qknorm(int dt, const void* A, int lda, const void* B
   g.Ttok = T;
   g.H = H;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_GEMM_FUSED, 2.0 * M * (double)(nparts * C) * K, 0.0, s);
+  ProfScope ps(NVIT_KID_GEMM_QKNORM, 2.0 * M * (double)(nparts * C) * K, 0.0, s);
   return nvit_gemm_nt_fused_launch(g, 4, s);
 }

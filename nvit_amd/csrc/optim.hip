@@ -289,7 +289,7 @@ extern "C" int nvit_grad_sqnorm(const int64_t* table, int n, int total_chunks, f
   NVIT_REQUIRE(table && partial && n > 0 && total_chunks > 0 && npart > 0 && npart <= 4096,
                "grad_sqnorm: bad arguments");
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_RENORM, 0.0, (double)total_chunks * OPT_CHUNK * 4.0, s);
+  ProfScope ps(NVIT_KID_OPTIM, 0.0, (double)total_chunks * OPT_CHUNK * 4.0, s);
   hipLaunchKernelGGL(grad_sqnorm_kernel, dim3(npart), dim3(256), 0, s, table, n, total_chunks, partial);
   NVIT_CHECK_LAUNCH("grad_sqnorm");
   return NVIT_OK;
@@ -322,7 +322,7 @@ extern "C" int nvit_adamw_renorm(const int64_t* table, int n, int total_items, i
     lds_set = lds;
   }
   int grid = total_items < 2048 ? total_items : 2048;
-  ProfScope ps(NVIT_KID_RENORM, 0.0, 0.0, s);
+  ProfScope ps(NVIT_KID_OPTIM, 0.0, 0.0, s);
   hipLaunchKernelGGL(adamw_renorm_kernel, dim3(grid), dim3(1024), lds, s, table, n, total_items, partial, a, gnorm_out, hyper);
   NVIT_CHECK_LAUNCH("adamw_renorm");
   return NVIT_OK;

@@ -15,7 +15,14 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void renorm_kernel(const int64_t* table, int n, int total_items) {
+// 1024-thread workgroups (16 waves per CU keep ~48 KiB of 16-byte loads in flight, which is what an HBM-bound
+// stream needs on this chip).  dim=1: one wave per row, the row stays in registers between the norm and the
+// scaled store (one read + one write per element, no second pass).  dim=0: [rows x 32] column slab in LDS.
+constexpr int RENORM_THREADS = 1024;
+constexpr int RENORM_RG = RENORM_THREADS / 8;   // row groups of the column pass
+constexpr int RENORM_NV = 8;                    // float4 per lane held in registers: rows of up to 2048 columns
+
+__global__ __launch_bounds__(RENORM_THREADS) void renorm_kernel(const int64_t* table, int n, int total_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
@@ -27,24 +34,27 @@ __global__ __launch_bounds__(256) void renorm_kernel(const int64_t* table, int n
     const int rows = (int)table[mi * 5 + 1], cols = (int)table[mi * 5 + 2], dim = (int)table[mi * 5 + 3];
     const int local = item - (int)table[mi * 5 + 4];
     if (dim == 1) {
-      const int r0 = local * NVIT_RENORM_ROWS_PER_ITEM;
-      for (int rr = wid; rr < NVIT_RENORM_ROWS_PER_ITEM; rr += 4) {
-        const int r = r0 + rr;
-        if (r >= rows) break;
+      const int r = local * NVIT_RENORM_ROWS_PER_ITEM + wid;   // NVIT_RENORM_ROWS_PER_ITEM == waves per workgroup
+      if (r < rows) {
         float* row = W + (size_t)r * cols;
-        float s = 0.f;
-        if ((cols & 3) == 0) {
-          for (int c = lane * 4; c < cols; c += 256) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
-            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        if ((cols & 3) == 0 && cols <= RENORM_NV * 256) {
+          f32x4 v[RENORM_NV];
+          float s = 0.f;
+#pragma unroll
+          for (int i = 0; i < RENORM_NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            v[i] = c < cols ? *reinterpret_cast<const f32x4*>(row + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s += v[i][0] * v[i][0] + v[i][1] * v[i][1] + v[i][2] * v[i][2] + v[i][3] * v[i][3];
           }
           s = wave_sum(s);
           const float nrm = sqrtf(s);
-          for (int c = lane * 4; c < cols; c += 256) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
-            *reinterpret_cast<f32x4*>(row + c) = v / nrm;
+#pragma unroll
+          for (int i = 0; i < RENORM_NV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            if (c < cols) *reinterpret_cast<f32x4*>(row + c) = v[i] / nrm;
           }
         } else {
+          float s = 0.f;
           for (int c = lane; c < cols; c += 64) s += row[c] * row[c];
           s = wave_sum(s);
           const float nrm = sqrtf(s);
@@ -54,11 +64,11 @@ __global__ __launch_bounds__(256) void renorm_kernel(const int64_t* table, int n
     } else {
       // column slab [rows][32] in LDS
       float* slab = reinterpret_cast<float*>(smem);
-      float* red = slab + (size_t)rows * NVIT_RENORM_COLS_PER_ITEM;  // [32][32]
+      float* red = slab + (size_t)rows * NVIT_RENORM_COLS_PER_ITEM;  // [RENORM_RG][32]
       const int c0 = local * NVIT_RENORM_COLS_PER_ITEM;
-      const int cg = (tid & 7) * 4, rg = tid >> 3;  // 8 threads cover 32 columns; 32 row groups
+      const int cg = (tid & 7) * 4, rg = tid >> 3;  // 8 threads cover 32 columns; RENORM_RG row groups
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int r = rg; r < rows; r += 32) {
+      for (int r = rg; r < rows; r += RENORM_RG) {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (c0 + cg + 3 < cols)
           v = *reinterpret_cast<const f32x4*>(W + (size_t)r * cols + c0 + cg);
@@ -72,12 +82,12 @@ __global__ __launch_bounds__(256) void renorm_kernel(const int64_t* table, int n
       __syncthreads();
       if (tid < 32) {
         float s = 0.f;
-        for (int g = 0; g < 32; ++g) s += red[g * 32 + tid];
+        for (int g = 0; g < RENORM_RG; ++g) s += red[g * 32 + tid];
         red[tid] = sqrtf(s);  // row 0 of red is only read by thread `tid` above before this write
       }
       __syncthreads();
       const f32x4 nrm = *reinterpret_cast<const f32x4*>(red + cg);
-      for (int r = rg; r < rows; r += 32) {
+      for (int r = rg; r < rows; r += RENORM_RG) {
         f32x4 v = *reinterpret_cast<const f32x4*>(slab + r * 32 + cg);
         v = v / nrm;
         if (c0 + cg + 3 < cols)
@@ -143,7 +153,8 @@ extern "C" int nvit_renorm_weights(const int64_t* table, int n, int total_items,
   NVIT_REQUIRE(n > 0 && total_items > 0, "renorm: empty table");
   hipStream_t s = (hipStream_t)stream;
   // LDS for the largest column slab: caller guarantees rows <= 1152 for dim=0 matrices.
-  static const int kMaxLds = 1152 * NVIT_RENORM_COLS_PER_ITEM * 4 + 32 * 32 * 4;
+  static_assert(NVIT_RENORM_ROWS_PER_ITEM == RENORM_THREADS / 64, "one row per wave per item");
+  static const int kMaxLds = 1152 * NVIT_RENORM_COLS_PER_ITEM * 4 + RENORM_RG * 32 * 4;   // = 160 KiB
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)renorm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
@@ -152,7 +163,7 @@ extern "C" int nvit_renorm_weights(const int64_t* table, int n, int total_items,
   }
   int grid = total_items < 1024 ? total_items : 1024;
   ProfScope ps(NVIT_KID_RENORM, 0.0, 0.0, s);
-  hipLaunchKernelGGL(renorm_kernel, dim3(grid), dim3(256), kMaxLds, s, table, n, total_items);
+  hipLaunchKernelGGL(renorm_kernel, dim3(grid), dim3(RENORM_THREADS), kMaxLds, s, table, n, total_items);
   NVIT_CHECK_LAUNCH("renorm");
   return NVIT_OK;
 }

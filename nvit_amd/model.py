@@ -195,7 +195,7 @@ class _Runtime:
 # --------------------------------------------------------------------------------------------
 def _attn_part_fwd(rt: _Runtime, impl: int, q_src, ldq, k_src, ldk, v_src, ldv, sqk, c_q, B, T, H, d):
     qh, kh, vh, rq, rk = ops.qknorm_fwd(rt.dt, q_src, ldq, k_src, ldk, v_src, ldv, sqk, c_q, B, T, H, d)
-    o, lse = ops.attn_fwd(rt.dt, impl, qh, kh, vh, math.sqrt(d))
+    o, lse = ops.attn_fwd(rt.dt, impl, qh, kh, vh, math.sqrt(d), sqk, c_q)
     return qh, kh, vh, rq, rk, o, lse
 
 
@@ -249,7 +249,7 @@ class _BlockFn(torch.autograd.Function):
         if not has_b and d == 64 and ops.fusable(dt, M, 3 * C, C):
             # q/k/v projection with the per-head normalise + sqk scale + head split in the GEMM epilogue
             qh, kh, vh, rq, rk = ops.gemm_nt_qknorm(x_lo, sh[pre + "qkv.W"], M, C, 3, 0, sqk, c_q, B, T, H, d)
-            o, lse = ops.attn_fwd(dt, impl, qh, kh, vh, math.sqrt(d))
+            o, lse = ops.attn_fwd(dt, impl, qh, kh, vh, math.sqrt(d), sqk, c_q)
         else:
             qkv = ops.gemm_nt(x_lo, sh[pre + "qkv.W"], M, 3 * C, C, out_dtype=td, bias=sh.get(pre + "qkv.b"))
             qh, kh, vh, rq, rk, o, lse = _attn_part_fwd(rt, impl, qkv, 3 * C, qkv[:, C:], 3 * C, qkv[:, 2 * C:],
@@ -384,7 +384,7 @@ class _CrossFn(torch.autograd.Function):
             bufs = ops.qk_buffers(dt, B, T, H, d, loc.device)
             ops.gemm_nt_qknorm(loc_lo, sh["x.q.W"], M, C, 1, 0, sqk, c_q, B, T, H, d, bufs)
             qh, kh, vh, rq, rk = ops.gemm_nt_qknorm(glo_lo, sh["x.kv.W"], M, C, 2, 1, sqk, c_q, B, T, H, d, bufs)
-            o, lse = ops.attn_fwd(dt, impl, qh, kh, vh, math.sqrt(d))
+            o, lse = ops.attn_fwd(dt, impl, qh, kh, vh, math.sqrt(d), sqk, c_q)
         else:
             q = ops.gemm_nt(loc_lo, sh["x.q.W"], M, C, C, out_dtype=td, bias=sh.get("x.q.b"))
             kv = ops.gemm_nt(glo_lo, sh["x.kv.W"], M, 2 * C, C, out_dtype=td, bias=sh.get("x.kv.b"))

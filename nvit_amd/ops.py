@@ -310,13 +310,19 @@ def scale_cols(a: Tensor, s: Tensor, c: float, R: int, N: int, out: Tensor, lda:
 
 
 # ----------------------------------------------------------------------------- attention
-def attn_fwd(dt: int, impl: int, qh: Tensor, kh: Tensor, vh: Tensor, scale: float):
+def attn_fwd(dt: int, impl: int, qh: Tensor, kh: Tensor, vh: Tensor, scale: float, sqk: Optional[Tensor] = None,
+             c_q: float = 0.0):
+    """sqk/c_q given: q and k are (sqk*c_q) * unit vectors per head (the nViT call sites) -> bounded-score kernel path."""
     B, H, Tq, d = qh.shape
     Tk = kh.shape[2]
     o = torch.empty((B * Tq, H * d), device=qh.device, dtype=tdtype(dt))
     lse = torch.empty((B, H, Tq), device=qh.device, dtype=torch.float32)
-    check(_lib.load().nvit_attn_fwd(dt, impl, _p(qh), _p(kh), _p(vh), scale, _p(o), _p(lse), B, H, Tq, Tk, d, _s()),
-          "nvit_attn_fwd")
+    if sqk is not None:
+        check(_lib.load().nvit_attn_fwd_bounded(dt, impl, _p(qh), _p(kh), _p(vh), scale, _p(sqk), c_q, _p(o), _p(lse), B,
+                                                H, Tq, Tk, d, _s()), "nvit_attn_fwd_bounded")
+    else:
+        check(_lib.load().nvit_attn_fwd(dt, impl, _p(qh), _p(kh), _p(vh), scale, _p(o), _p(lse), B, H, Tq, Tk, d, _s()),
+              "nvit_attn_fwd")
     return o, lse
 
 

@@ -12,6 +12,12 @@ in two HIP launches (`nvit_grad_sqnorm`, `nvit_adamw_renorm`) over a device-side
 p, g, m, v once and writing p, m, v once.  Plain `step()` (no clip, no renorm) uses the same kernel, so code that
 calls `optimizer.step()` followed by `normalize_matrices(model)` gives identical weights.  There is no torch
 fallback: the parameters must live on the HIP device.
+
+One step counter serves all parameters (it lives on the device so that a captured step replays correctly).  torch
+keeps one per parameter; the two agree as long as every parameter that is ever updated receives a gradient from the
+first step on - true for this model, whose never-updated parameters (rmsnorm_*, the recon head without the Kohonen
+loss) never get a gradient at all.  A parameter whose first gradient arrives late would be bias-corrected with the
+global count; `_loaded_step` refuses checkpoints whose per-parameter counts disagree.
 """
 from __future__ import annotations
 
@@ -42,6 +48,8 @@ class FusedAdamW(torch.optim.AdamW):
         self._t = 0          # optimizer steps taken (host mirror of the device counter hyper[0])
         self._hyper = None   # device float[3]: step, 1/(1-b1^t), 1/sqrt(1-b2^t) - maintained by nvit_adamw_tick
         self._staging = None  # pinned host image of the device table
+        self._hyper_pin = None   # pinned image of the lr/weight_decay column (eager lr schedules)
+        self._hyper_ev = None
 
     # ------------------------------------------------------------------ state
     def _ensure_state(self, p: torch.Tensor) -> Dict:
@@ -56,6 +64,7 @@ class FusedAdamW(torch.optim.AdamW):
         """Device table for the current (param, grad, state) pointers; rebuilt only when one of them moves."""
         rows: List[List[int]] = []
         key = []
+        hypers: List[int] = []   # per row: lr | weight_decay bits (column 9 of the table)
         first_item = first_chunk = 0
         max_slab_rows = 0
         beta_eps = None
@@ -97,10 +106,15 @@ class FusedAdamW(torch.optim.AdamW):
                     hyper -= 1 << 64
                 rows.append([p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(),
                              r, c, kind, first_item, first_chunk, hyper])
-                key.append((p.data_ptr(), g.data_ptr(), kind, group["lr"], group["weight_decay"]))
+                key.append((p.data_ptr(), g.data_ptr(), kind))
+                hypers.append(hyper)
                 first_item += items
                 first_chunk += math.ceil(p.numel() / _CHUNK)
         key = tuple(key)
+        if self._cache is not None and self._cache["key"] == key and self._cache["hypers"] != hypers:
+            # only lr / weight_decay moved (the reference trainer rewrites lr every iteration): update the hyper column in
+            # place instead of rebuilding table, workspaces and a pinned image
+            self._write_hyper_column(hypers)
         if self._cache is None or self._cache["key"] != key:
             if not rows:
                 return None
@@ -131,6 +145,7 @@ class FusedAdamW(torch.optim.AdamW):
                 staged = False
             self._cache = {
                 "key": key,
+                "hypers": hypers,
                 "table": table,
                 "n": len(rows), "items": first_item, "chunks": first_chunk, "slab": max_slab_rows,
                 "partial": torch.empty(_NPART, device=dev, dtype=torch.float32),
@@ -192,13 +207,32 @@ class FusedAdamW(torch.optim.AdamW):
                 t = v
         return t or 0
 
+    def _write_hyper_column(self, hypers: List[int]) -> None:
+        c = self._cache
+        hcol = torch.tensor(hypers, dtype=torch.int64)
+        if c["staged"]:
+            torch.cuda.current_stream().synchronize()   # no replay may be reading the staging buffer while it changes
+            self._staging[:c["n"], 9].copy_(hcol)
+            c["table"].copy_(self._staging[:c["n"]], non_blocking=True)
+        else:
+            # one persistent pinned column, guarded by an event: the previous async copy must have left it
+            if self._hyper_pin is None or self._hyper_pin.numel() < c["n"]:
+                self._hyper_pin = torch.empty(max(c["n"], 64), dtype=torch.int64).pin_memory()
+                self._hyper_ev = torch.cuda.Event()
+            else:
+                self._hyper_ev.synchronize()
+            self._hyper_pin[:c["n"]].copy_(hcol)
+            c["table"][:, 9].copy_(self._hyper_pin[:c["n"]], non_blocking=True)
+            self._hyper_ev.record()
+        c["hypers"] = list(hypers)
+
     def rewrite_hyper(self) -> None:
         """Push the param groups' current lr / weight_decay into the device table in place (same addresses, so a
         captured step picks them up on its next replay)."""
         c = self._cache
         if c is None:
             return
-        col, i = [], 0
+        col = []
         for group in self.param_groups:
             hyper = _f32_bits(group["lr"]) | (_f32_bits(group["weight_decay"]) << 32)
             if hyper >= 1 << 63:
@@ -208,15 +242,7 @@ class FusedAdamW(torch.optim.AdamW):
                     col.append(hyper)
         if len(col) != c["n"]:
             raise RuntimeError("FusedAdamW.rewrite_hyper: parameter set changed since the table was built")
-        hcol = torch.tensor(col, dtype=torch.int64)
-        if c["staged"]:
-            torch.cuda.current_stream().synchronize()   # no replay may be reading the staging buffer while it changes
-            self._staging[:c["n"], 9].copy_(hcol)
-            c["table"].copy_(self._staging[:c["n"]], non_blocking=True)
-        else:
-            c["table"][:, 9].copy_(hcol.pin_memory(), non_blocking=True)
-        groups = [g for g in self.param_groups for p in g["params"] if p.grad is not None]
-        c["key"] = tuple((k[0], k[1], k[2], g["lr"], g["weight_decay"]) for k, g in zip(c["key"], groups))
+        self._write_hyper_column(col)
 
     def reserve_staging(self) -> None:
         """Pinned host image for the parameter table, allocated ahead of a hipGraph capture."""

@@ -62,9 +62,13 @@ def test_dp_two_ranks_real_model(tmp_path):
         # torch's own ops produce (biases, position embeddings, LayerNorm, head) are still copied
         assert r["copies_step1"] == r["copies_step2"] <= 12 < r["n_grads"], r
     r0 = res[0]
-    assert r0["grad_err_vs_single_process"] < 2e-5, r0
-    assert r0["param_err_vs_single_process"] < 2e-6, r0
-    assert r0["accum_err_vs_single_process"] < 2e-5, r0
+    # step 0: same parameters on both sides -> only the summation order of the batch halves differs.  Later steps: the
+    # first Adam steps are sign-like (g / sqrt(g^2)), so gradients that are zero up to rounding move a weight by a
+    # fraction of lr = 1e-3 in either direction; the runs then differ by that much, not more.
+    assert r0["grad_err_vs_single_process"][0] < 5e-6, r0
+    assert max(r0["grad_err_vs_single_process"]) < 3e-4, r0
+    assert r0["param_err_vs_single_process"] < 1e-4, r0
+    assert r0["accum_err_vs_single_process"] < 3e-4, r0
 
 
 def test_dp_two_ranks_kohonen_head(tmp_path):

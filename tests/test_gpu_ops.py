@@ -250,6 +250,47 @@ def test_attention(dtype, impl, B, H, T, d):
         assert e < lim, f"{name}: err {e:.3e} >= {lim:.3e}"
 
 
+@pytest.mark.parametrize("B,H,T", [(2, 3, 784), (1, 2, 130), (1, 1, 16), (2, 2, 64)])
+@pytest.mark.parametrize("smul", [1.0, 1.6, 3.0])
+def test_attention_bounded_scores(B, H, T, smul):
+    """nvit_attn_fwd_bounded: q, k = (sqk*c_q) * unit vectors (the nViT form).  smul 1.0 / 1.6: the bound-relative fast
+    path (no running max); smul 3.0: the bound exceeds the safe range and the kernel falls back to the online softmax.
+    Against fp32 torch math and against the generic entry point on the same inputs."""
+    ops = ops_()
+    from nvit_amd._lib import BF16
+    d = 64
+    C = H * d
+    c_q = 32.0
+    sqk = (smul / 32.0) * (1.0 + 0.3 * torch.tanh(rnd(C, seed=7)))
+    s_eff = (sqk * c_q).reshape(1, H, 1, d)
+    q = (s_eff * torch.nn.functional.normalize(rnd(B, H, T, d, seed=1), dim=-1)).bfloat16()
+    k = (s_eff * torch.nn.functional.normalize(rnd(B, H, T, d, seed=2), dim=-1)).bfloat16()
+    v = rnd(B, H, T, d, seed=3).bfloat16()
+    scale = math.sqrt(d)
+    o_ref, lse_ref = _sdpa_ref(q.float(), k.float(), v.float(), scale)
+    dv_ = dev()
+    o, lse = ops.attn_fwd(BF16, 1, q.to(dv_), k.to(dv_), v.to(dv_), scale, sqk.to(dv_), c_q)
+    o2, lse2 = ops.attn_fwd(BF16, 1, q.to(dv_), k.to(dv_), v.to(dv_), scale)
+    o_bhtd = o.float().cpu().reshape(B, T, H, d).permute(0, 2, 1, 3)
+    # (on the fast path the row sum is taken by the MFMA pipe over the bf16-rounded probabilities - the same values the
+    #  output is built from, so O stays a properly normalised average - which moves lse by up to 2^-9 (one dominant key) in absolute terms)
+    lse_tol = 4e-3 if smul < 3.0 else 1e-4 * max(1.0, lse_ref.abs().max().item())
+    o_tol = 1e-2 + 2.0 ** -7 * o_ref.abs().max().item()   # + one bf16 ulp of the stored output at its largest magnitude
+    assert (o_bhtd - o_ref).abs().max().item() < o_tol
+    assert (lse.cpu() - lse_ref).abs().max().item() < lse_tol
+    assert (o.float() - o2.float()).abs().max().item() < o_tol
+    assert (lse - lse2).abs().max().item() < lse_tol
+    # spike: one key aligned with one query at the largest possible score (the bound itself) must not overflow
+    q2, k2 = q.clone(), k.clone()
+    k2[0, 0, T // 2] = q2[0, 0, 0]
+    o3, lse3 = ops.attn_fwd(BF16, 1, q2.to(dv_), k2.to(dv_), v.to(dv_), scale, sqk.to(dv_), c_q)
+    o3_ref, lse3_ref = _sdpa_ref(q2.float(), k2.float(), v.float(), scale)
+    assert torch.isfinite(o3.float()).all() and torch.isfinite(lse3).all()
+    # (the spiked row copies one V row, |v| up to ~4)
+    assert (o3.float().cpu().reshape(B, T, H, d).permute(0, 2, 1, 3) - o3_ref).abs().max().item() < 1e-2 + 2.0 ** -7 * o3_ref.abs().max().item()
+    assert (lse3.cpu() - lse3_ref).abs().max().item() < lse_tol
+
+
 def test_im2col_pool_recon():
     ops = ops_()
     from nvit_amd._lib import F32
