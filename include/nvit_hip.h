@@ -65,9 +65,9 @@ const char* nvit_prof_name(int kid);
  * (att_c_proj/mlp_c_proj).  fp32 in place, one read + one write per element.
  * first_item = prefix sum of work items (rows/NVIT_RENORM_ROWS_PER_ITEM for dim=1,
  * cols/NVIT_RENORM_COLS_PER_ITEM for dim=0, rounded up); total_items = sum.
- * dim=0 needs rows*NVIT_RENORM_COLS_PER_ITEM*4 bytes <= 144 KiB of LDS (rows <= 1152). */
-#define NVIT_RENORM_ROWS_PER_ITEM 16
-#define NVIT_RENORM_COLS_PER_ITEM 32
+ * dim=0 keeps a [rows x NVIT_RENORM_COLS_PER_ITEM] panel in the registers of a 1024-thread workgroup (rows <= 1152). */
+#define NVIT_RENORM_ROWS_PER_ITEM 64
+#define NVIT_RENORM_COLS_PER_ITEM 64
 int nvit_renorm_weights(const int64_t* table, int n, int total_items, void* stream);
 
 /* nvit_shadow_weights: builds the private MFMA-operand copies of the fp32 master weights
@@ -79,7 +79,10 @@ int nvit_renorm_weights(const int64_t* table, int n, int total_items, void* stre
  *   Either dst or dstT may be 0 (skipped).  dst/dstT may point inside a larger concatenated
  *   buffer (Q|K|V stacking); only the stated extents are written.
  *   perm: 0 identity; 1 = SwiGLU interleave of a [2F, K] matrix: shadow row 32q+w is
- *         source row 16q+w (w<16, "u") or F+16q+(w-16) (w>=16, "v").
+ *         source row 16q+w (w<16, "u") or F+16q+(w-16) (w>=16, "v");
+ *         2 = split-precision image (dt = bf16 only, dstT unused): dst [rows, 3*cols] = [hi | hi | lo] with
+ *         hi = bf16(src), lo = bf16(src - hi) - the weight operand of the patch-embedding GEMM whose
+ *         activation rows nvit_im2col writes as [hi | lo | hi] (dt NVIT_BF16X3).
  *   Work items are 64x64 tiles: tiles_c = ceil(max(cols,dst_cols)/64) tile columns,
  *   ceil(max(rows,dstT_cols)/64) tile rows; first_item = prefix sum; total_items = sum.
  * Element type of dst/dstT is `dt`. */

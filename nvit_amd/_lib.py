@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libnvit_hip.so")
 F32, BF16, BF16X3 = 0, 1, 2
 KID_NAMES = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "rowops", "renorm", "shadow", "patchify", "misc", "gemm_f32",
              "gemm_swiglu", "gemm_qknorm", "gemm_swiglu_bwd", "optim"]
-RENORM_ROWS_PER_ITEM = 16
-RENORM_COLS_PER_ITEM = 32
+RENORM_ROWS_PER_ITEM = 64
+RENORM_COLS_PER_ITEM = 64
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 

@@ -5,8 +5,8 @@
 // minimum traffic (one HBM read + one write per element):
 //   dim=1 (row norms, query/key/value/c_fc): one wave per row; the second pass over the row
 //         (<= 16 KiB) is served by L1/L2.
-//   dim=0 (column norms, att_c_proj/mlp_c_proj): a workgroup keeps a [rows x 32-column] slab
-//         in LDS (<= 144 KiB of the CU's 160 KiB), so the column pass needs no re-read.
+//   dim=0 (column norms, att_c_proj/mlp_c_proj): a workgroup keeps a [rows x 64-column] panel
+//         in registers (rows <= 1152), so the column pass needs no re-read.
 //
 // shadow_kernel: builds the private MFMA-operand copies of the fp32 masters: W (optionally
 // row-permuted for the SwiGLU interleave) and W^T, cast to bf16 (or kept fp32 for the exact
@@ -15,27 +15,37 @@
 
 namespace {
 
+// row of the device table whose work-item range contains `item` (first_item column `col`, `stride` int64 per row):
+// binary search - a linear scan costs one dependent scalar load per matrix (72 for Base) in front of every item
+__device__ __forceinline__ int table_row(const int64_t* table, int n, int stride, int col, int item) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((int)table[mid * stride + col] <= item) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
 // 1024-thread workgroups (16 waves per CU keep ~48 KiB of 16-byte loads in flight, which is what an HBM-bound
 // stream needs on this chip).  dim=1: one wave per row, the row stays in registers between the norm and the
-// scaled store (one read + one write per element, no second pass).  dim=0: [rows x 32] column slab in LDS.
+// scaled store (one read + one write per element, no second pass).  dim=0: [rows x 64] column panel in registers.
 constexpr int RENORM_THREADS = 1024;
-constexpr int RENORM_RG = RENORM_THREADS / 8;   // row groups of the column pass
+constexpr int RENORM_CL = NVIT_RENORM_COLS_PER_ITEM / 4;   // lanes across a panel row (16-byte pieces)
+constexpr int RENORM_RG = RENORM_THREADS / RENORM_CL;   // row groups of the column pass
 constexpr int RENORM_NV = 8;                    // float4 per lane held in registers: rows of up to 2048 columns
+constexpr int RENORM_NR = 1152 / RENORM_RG;      // rows per thread of a column panel: matrices of up to 1152 rows
 
 __global__ __launch_bounds__(RENORM_THREADS) void renorm_kernel(const int64_t* table, int n, int total_items) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
-    int mi = 0;
-    for (int i = 1; i < n; ++i) {
-      if (item >= (int)table[i * 5 + 4]) mi = i; else break;
-    }
+    const int mi = table_row(table, n, 5, 4, item);
     float* W = reinterpret_cast<float*>(table[mi * 5 + 0]);
     const int rows = (int)table[mi * 5 + 1], cols = (int)table[mi * 5 + 2], dim = (int)table[mi * 5 + 3];
     const int local = item - (int)table[mi * 5 + 4];
     if (dim == 1) {
-      const int r = local * NVIT_RENORM_ROWS_PER_ITEM + wid;   // NVIT_RENORM_ROWS_PER_ITEM == waves per workgroup
-      if (r < rows) {
+      for (int r = local * NVIT_RENORM_ROWS_PER_ITEM + wid; r < rows && r < (local + 1) * NVIT_RENORM_ROWS_PER_ITEM;
+           r += RENORM_THREADS / 64) {
         float* row = W + (size_t)r * cols;
         if ((cols & 3) == 0 && cols <= RENORM_NV * 256) {
           f32x4 v[RENORM_NV];
@@ -62,39 +72,59 @@ __global__ __launch_bounds__(RENORM_THREADS) void renorm_kernel(const int64_t* t
         }
       }
     } else {
-      // column slab [rows][32] in LDS
-      float* slab = reinterpret_cast<float*>(smem);
-      float* red = slab + (size_t)rows * NVIT_RENORM_COLS_PER_ITEM;  // [RENORM_RG][32]
-      const int c0 = local * NVIT_RENORM_COLS_PER_ITEM;
-      const int cg = (tid & 7) * 4, rg = tid >> 3;  // 8 threads cover 32 columns; RENORM_RG row groups
+      // [rows x 64]-column panel (256-byte row segments) held in REGISTERS (thread = 4 columns x every 64th row):
+      // all loads go out before the reduction, only the partial sums cross LDS
+      constexpr int PC = NVIT_RENORM_COLS_PER_ITEM;
+      float* red = reinterpret_cast<float*>(smem);  // [RENORM_RG][PC]
+      const int c0 = local * PC;
+      const int cg = (tid % RENORM_CL) * 4, rg = tid / RENORM_CL;  // RENORM_CL threads cover a panel row; RENORM_RG row groups
+      const bool vec = c0 + cg + 3 < cols;
+      f32x4 v[RENORM_NR];
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      for (int r = rg; r < rows; r += RENORM_RG) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c0 + cg + 3 < cols)
-          v = *reinterpret_cast<const f32x4*>(W + (size_t)r * cols + c0 + cg);
-        else
-          for (int e = 0; e < 4; ++e)
-            if (c0 + cg + e < cols) v[e] = W[(size_t)r * cols + c0 + cg + e];
-        *reinterpret_cast<f32x4*>(slab + r * 32 + cg) = v;
-        acc += v * v;
+#pragma unroll
+      for (int i = 0; i < RENORM_NR; ++i) {
+        const int r = rg + i * RENORM_RG;
+        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+          if (vec)
+            v[i] = *reinterpret_cast<const f32x4*>(W + (size_t)r * cols + c0 + cg);
+          else
+            for (int e = 0; e < 4; ++e)
+              if (c0 + cg + e < cols) v[i][e] = W[(size_t)r * cols + c0 + cg + e];
+        }
+        acc += v[i] * v[i];
       }
-      *reinterpret_cast<f32x4*>(red + rg * 32 + cg) = acc;
+      *reinterpret_cast<f32x4*>(red + rg * PC + cg) = acc;
       __syncthreads();
-      if (tid < 32) {
+      // fixed-order two-level sum of the row-group partials: 8 parts per column, then 8
+      float* red2 = red + RENORM_RG * PC;  // [8][PC] + [PC]
+      if (tid < 8 * PC) {
+        const int c = tid % PC, part = tid / PC;
         float s = 0.f;
-        for (int g = 0; g < RENORM_RG; ++g) s += red[g * 32 + tid];
-        red[tid] = sqrtf(s);  // row 0 of red is only read by thread `tid` above before this write
+#pragma unroll
+        for (int g = 0; g < RENORM_RG / 8; ++g) s += red[(part * (RENORM_RG / 8) + g) * PC + c];
+        red2[part * PC + c] = s;
       }
       __syncthreads();
-      const f32x4 nrm = *reinterpret_cast<const f32x4*>(red + cg);
-      for (int r = rg; r < rows; r += RENORM_RG) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(slab + r * 32 + cg);
-        v = v / nrm;
-        if (c0 + cg + 3 < cols)
-          *reinterpret_cast<f32x4*>(W + (size_t)r * cols + c0 + cg) = v;
-        else
-          for (int e = 0; e < 4; ++e)
-            if (c0 + cg + e < cols) W[(size_t)r * cols + c0 + cg + e] = v[e];
+      if (tid < PC) {
+        float s = 0.f;
+#pragma unroll
+        for (int part = 0; part < 8; ++part) s += red2[part * PC + tid];
+        red2[8 * PC + tid] = sqrtf(s);
+      }
+      __syncthreads();
+      const f32x4 nrm = *reinterpret_cast<const f32x4*>(red2 + 8 * PC + cg);
+#pragma unroll
+      for (int i = 0; i < RENORM_NR; ++i) {
+        const int r = rg + i * RENORM_RG;
+        if (r < rows) {
+          const f32x4 o = v[i] / nrm;
+          if (vec)
+            *reinterpret_cast<f32x4*>(W + (size_t)r * cols + c0 + cg) = o;
+          else
+            for (int e = 0; e < 4; ++e)
+              if (c0 + cg + e < cols) W[(size_t)r * cols + c0 + cg + e] = o[e];
+        }
       }
       __syncthreads();
     }
@@ -113,10 +143,7 @@ __global__ __launch_bounds__(256) void shadow_kernel(const int64_t* table, int n
   __shared__ float tile[64][65];
   const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
   for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
-    int mi = 0;
-    for (int i = 1; i < n; ++i) {
-      if (item >= (int)table[i * 12 + 10]) mi = i; else break;
-    }
+    const int mi = table_row(table, n, 12, 10, item);
     const int64_t* e = table + mi * 12;
     const float* src = reinterpret_cast<const float*>(e[0]);
     const int rows = (int)e[1], cols = (int)e[2];
@@ -131,12 +158,28 @@ __global__ __launch_bounds__(256) void shadow_kernel(const int64_t* table, int n
     for (int i = 0; i < 16; ++i) {
       const int r = r0 + ty + 4 * i, c = c0 + tx;
       float v = 0.f;
+      if (perm == 2) {
+        // split-precision image of a patch-embedding weight: [hi | hi | lo] with hi = bf16(w), lo = bf16(w - hi) - the
+        // partner of the im2col rows [hi | lo | hi], so ONE bf16 GEMM over 3K sums hi*hi + lo*hi + hi*lo (model.py)
+        if constexpr (sizeof(T) == 2) {
+          if (r < rows && c < cols) {
+            v = src[(size_t)r * cols + c];
+            const T hi = (T)v;
+            const T lo = (T)(v - (float)hi);
+            T* d = dst + (size_t)r * dst_ld + c;
+            d[0] = hi;
+            d[cols] = hi;
+            d[2 * cols] = lo;
+          }
+        }
+        continue;
+      }
       if (r < rows && c < cols) v = src[(size_t)shadow_perm_row(perm, r, rows / 2) * cols + c];
       tile[ty + 4 * i][tx] = v;
       if (dst && r < rows && c < dst_cols) dst[(size_t)r * dst_ld + c] = (T)v;
     }
     __syncthreads();
-    if (dstT) {
+    if (dstT && perm != 2) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int c = c0 + ty + 4 * i, r = r0 + tx;
@@ -153,15 +196,15 @@ extern "C" int nvit_renorm_weights(const int64_t* table, int n, int total_items,
   NVIT_REQUIRE(n > 0 && total_items > 0, "renorm: empty table");
   hipStream_t s = (hipStream_t)stream;
   // LDS for the largest column slab: caller guarantees rows <= 1152 for dim=0 matrices.
-  static_assert(NVIT_RENORM_ROWS_PER_ITEM == RENORM_THREADS / 64, "one row per wave per item");
-  static const int kMaxLds = 1152 * NVIT_RENORM_COLS_PER_ITEM * 4 + RENORM_RG * 32 * 4;   // = 160 KiB
+  static_assert(NVIT_RENORM_ROWS_PER_ITEM % (RENORM_THREADS / 64) == 0, "whole rounds of one row per wave");
+  static const int kMaxLds = (RENORM_RG + 9) * NVIT_RENORM_COLS_PER_ITEM * 4;   // partial sums only (~18 KiB)
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)renorm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
     if (e != hipSuccess) NVIT_FAIL((int)e, "renorm: cannot raise LDS limit: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  int grid = total_items < 1024 ? total_items : 1024;
+  int grid = total_items < 2048 ? total_items : 2048;
   ProfScope ps(NVIT_KID_RENORM, 0.0, 0.0, s);
   hipLaunchKernelGGL(renorm_kernel, dim3(grid), dim3(RENORM_THREADS), kMaxLds, s, table, n, total_items);
   NVIT_CHECK_LAUNCH("renorm");

@@ -134,8 +134,12 @@ class _Runtime:
 
         Kl = cfg.channels * cfg.local_patch_size ** 2
         Kg = cfg.channels * cfg.global_patch_size ** 2
-        ent.append((w2(m.local_patch_embed.weight), new("pe_l", C, Kl), Kl, Kl, None, 0, 0, 0))
-        ent.append((w2(m.global_patch_embed[1].weight), new("pe_g", C, Kg), Kg, Kg, None, 0, 0, 0))
+        if dt == F32:
+            ent.append((w2(m.local_patch_embed.weight), new("pe_l", C, Kl), Kl, Kl, None, 0, 0, 0))
+            ent.append((w2(m.global_patch_embed[1].weight), new("pe_g", C, Kg), Kg, Kg, None, 0, 0, 0))
+        else:   # split-precision [hi | hi | lo] images, K' = 3K (see _EmbedFn)
+            ent.append((w2(m.local_patch_embed.weight), new("pe_l", C, 3 * Kl), 3 * Kl, Kl, None, 0, 0, 2))
+            ent.append((w2(m.global_patch_embed[1].weight), new("pe_g", C, 3 * Kg), 3 * Kg, Kg, None, 0, 0, 2))
 
         def stack(prefix, lins, perm=0):
             """shadow of row-stacked Linear weights [sum rows, K] and its transpose [K, sum rows]."""
@@ -460,13 +464,6 @@ class _CrossFn(torch.autograd.Function):
                 g_bproj, g_bout)
 
 
-def _split3_weight(w: torch.Tensor) -> torch.Tensor:
-    """[N,K] fp32 -> [N,3K] bf16 image [hi | hi | lo] (partner of the im2col [hi | lo | hi] rows)."""
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.to(torch.float32)).to(torch.bfloat16)
-    return torch.cat((hi, hi, lo), dim=1)
-
-
 class _EmbedFn(torch.autograd.Function):
     """Dual patch embedding + position embeddings (reference model.py:407-415) as im2col GEMMs."""
 
@@ -492,10 +489,9 @@ class _EmbedFn(torch.autograd.Function):
             glo = ops.gemm_nt(A_g, rt.sh["pe_g"], M, C, Kg, bias=bg, rowadd=posg.reshape(T, C), rowadd_period=T)
         else:
             A_l, A_g = ops.im2col(BF16X3, img, Pl, Pg)
-            loc = ops.gemm_nt(A_l, _split3_weight(wl.reshape(C, -1)), M, C, 3 * Kl, bias=bl,
-                              rowadd=posl.reshape(T, C), rowadd_period=T)
-            glo = ops.gemm_nt(A_g, _split3_weight(wg.reshape(C, -1)), M, C, 3 * Kg, bias=bg,
-                              rowadd=posg.reshape(T, C), rowadd_period=T)
+            # (the [hi | hi | lo] weight images are part of the shadow set, built by nvit_shadow_weights)
+            loc = ops.gemm_nt(A_l, rt.sh["pe_l"], M, C, 3 * Kl, bias=bl, rowadd=posl.reshape(T, C), rowadd_period=T)
+            glo = ops.gemm_nt(A_g, rt.sh["pe_g"], M, C, 3 * Kg, bias=bg, rowadd=posg.reshape(T, C), rowadd_period=T)
         ctx.rt = rt
         ctx.dims = (B, T, C, M, Kl, Kg)
         ctx.par = (wl, wg)

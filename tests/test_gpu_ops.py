@@ -105,6 +105,22 @@ def test_renorm_and_shadow():
         assert torch.equal(dstT.float().cpu()[:, 100:], torch.full((40, 28), 9.0))
 
 
+def test_shadow_split_precision_image():
+    """perm=2: [hi | hi | lo] bf16 image of a patch-embedding weight; hi + lo reproduces the fp32 value to 2^-16."""
+    ops = ops_()
+    from nvit_amd._lib import BF16
+    w = rnd(100, 72, seed=9, scale=0.1)
+    dst = torch.full((100, 3 * 72), 9.0, device=dev(), dtype=torch.bfloat16)
+    t, n = ops.shadow_table([(w.to(dev()), dst, 3 * 72, 72, None, 0, 0, 2)], dev())
+    ops.shadow_weights(t, n, BF16)
+    got = dst.float().cpu()
+    hi = w.bfloat16()
+    lo = (w - hi.float()).bfloat16()
+    assert torch.equal(got[:, :72], hi.float()) and torch.equal(got[:, 72:144], hi.float())
+    assert torch.equal(got[:, 144:], lo.float())
+    assert (got[:, :72] + got[:, 144:] - w).abs().max().item() < 2.0 ** -16 * w.abs().max().item()
+
+
 @pytest.mark.parametrize("C", [64, 192, 768, 1024])
 @pytest.mark.parametrize("with_skip", [False, True])
 def test_lerp_fwd_bwd(C, with_skip):
