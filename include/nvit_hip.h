@@ -228,7 +228,7 @@ int nvit_attn_fwd(int dt, int impl, const void* qh, const void* kh, const void* 
  * probabilities relative to the bound instead of a running maximum (no per-tile max / rescale).  sqk: [H*d] fp32. */
 int nvit_attn_fwd_bounded(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, const float* sqk,
                           float c_q, void* o, float* lse, int B, int H, int Tq, int Tk, int d, void* stream);
-/* delta [B,H,T] workspace fp32. dqh,dkh,dvh [B,H,T,d] type dt. */
+/* delta: [2,B,H,Tq] fp32 workspace (rowsum(dO*O), and lse in log2 units for the dk/dv kernel). dqh,dkh,dvh [B,H,T,d] type dt. */
 int nvit_attn_bwd(int dt, int impl, const void* dout, const void* qh, const void* kh, const void* vh, const void* o,
                   const float* lse, float scale, void* dqh, void* dkh, void* dvh, float* delta, int B, int H,
                   int Tq, int Tk, int d, void* stream);

@@ -68,6 +68,33 @@ __device__ __forceinline__ uint4 pack8(const f32x4& a, const f32x4& b) {
   return __builtin_bit_cast(uint4, v);
 }
 
+__device__ __forceinline__ uint2 pack4(const f32x4& a) {
+  bf16x4 v = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3]};
+  return __builtin_bit_cast(uint2, v);
+}
+
+// Store a wave's [32 rows x 64] result held in accumulator layout (g[df][f][r] = out[row 16f + l15][col 16df + 4lg + r])
+// as bf16 rows of 128 bytes: through a wave-private 4 KiB LDS scratch (XOR-swizzled like the K/V tiles) so that every
+// global store instruction writes whole 128-byte rows, 16 bytes per lane (4 instructions per wave), instead of eight
+// instructions of 8-byte pieces that each touch a quarter of 16 different rows.  dst -> element (row 0, col 0) of the
+// tile, ld = row stride in elements, rows >= nvalid are not written.
+__device__ __forceinline__ void store_tile32x64(const f32x4 (&g)[4][2], char* scr, bf16* dst, size_t ld, int nvalid,
+                                                int lane) {
+  const int l15 = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+      *reinterpret_cast<uint2*>(scr + swz_off(16 * f + l15, 2 * df + (lg >> 1)) + 8 * (lg & 1)) = pack4(g[df][f]);
+  __builtin_amdgcn_wave_barrier();   // DS instructions of one wave execute in order; this only pins the compiler
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = pass * 8 + (lane >> 3), chunk = lane & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(scr + swz_off(row, chunk));
+    if (row < nvalid) *reinterpret_cast<uint4*>(dst + (size_t)row * ld + chunk * 8) = v;
+  }
+}
+
 // stage one 64-row tile (rows of 64 bf16) from `src` (row stride ld elements) : each thread 2 chunks
 struct Stage2 {
   uint4 v[2];
@@ -101,18 +128,41 @@ __device__ __forceinline__ void glds16a(const void* gsrc, unsigned lds_off) {
       : "v"(gsrc), "s"(m)
       : "memory");
 }
-// DMA one 64-row tile of `src` (row stride ld elements, rows clamped to nrows-1) to LDS byte offset tile_off;
-// 4 waves x 2 wave-instructions.  TILE_DMA = instructions per wave per tile.
+// Same with the source address split into a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset:
+// the per-tile part of the address (which tile) then lives in scalar registers and costs no VALU issue slots - these
+// kernels are VALU-issue bound (PMC: VALU + MFMA issue ~ 87 % of the SIMD cycles), so address arithmetic is not free.
+__device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_off) {
+  unsigned keep;
+  const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_off);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(m)
+      : "memory");
+}
+// DMA one 64-row tile of `src` (row stride ld_bytes, rows clamped to nrows-1) to LDS byte offset tile_off;
+// 4 waves x 2 wave-instructions.  TILE_DMA = instructions per wave per tile.  `src`, row_base and nrows are wave
+// uniform; voff[i] = tile_voff(i, ...) are the lane's offsets inside a full tile, computed once per kernel.
 constexpr int TILE_DMA = 2;
-__device__ __forceinline__ void tile_dma(const bf16* src, size_t ld, int row_base, int nrows, unsigned tile_off,
-                                         int lane, int wid) {
+__device__ __forceinline__ unsigned tile_voff(int i, unsigned ld_bytes, int lane, int wid) {
   const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
+  return (unsigned)((i * 4 + wid) * 8 + r8) * ld_bytes + (unsigned)chunk * 16u;
+}
+__device__ __forceinline__ void tile_dma(const bf16* src, unsigned ld_bytes, int row_base, int nrows, unsigned tile_off,
+                                         int lane, int wid, const unsigned (&voff)[TILE_DMA]) {
+  const char* sb = reinterpret_cast<const char*>(src) + (size_t)row_base * ld_bytes;
+  if (row_base + TKV <= nrows) {
 #pragma unroll
-  for (int i = 0; i < TILE_DMA; ++i) {
-    const int grp = i * 4 + wid;
-    int row = row_base + grp * 8 + r8;
-    row = row < nrows ? row : nrows - 1;
-    glds16a(src + (size_t)row * ld + chunk * 8, tile_off + grp * 1024);
+    for (int i = 0; i < TILE_DMA; ++i) glds16s(sb, voff[i], tile_off + (i * 4 + wid) * 1024);
+  } else {   // ragged last tile: rows past the end re-read the last valid row (finite values, masked by the consumer)
+    const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
+#pragma unroll
+    for (int i = 0; i < TILE_DMA; ++i) {
+      const int grp = i * 4 + wid;
+      int row = grp * 8 + r8;
+      row = row_base + row < nrows ? row : nrows - 1 - row_base;
+      glds16s(sb, (unsigned)row * ld_bytes + (unsigned)chunk * 16u, tile_off + grp * 1024);
+    }
   }
 }
 // Make the compiler retire its own pending global loads of `v` HERE (it inserts the s_waitcnt in front of this empty
@@ -187,11 +237,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
   const int nt = (Tk + TKV - 1) / TKV;
   // K/V ring: LDS-DMA two tiles ahead, counted vmcnt (4 younger DMA instructions may stay in flight)
   const unsigned ring = lds_addr(&lds[0][0][0]);
-  tile_dma(kbase, D, 0, Tk, ring, lane, wid);
-  tile_dma(vbase, D, 0, Tk, ring + TILE_BYTES, lane, wid);
+  const unsigned voff[TILE_DMA] = {tile_voff(0, ROWB, lane, wid), tile_voff(1, ROWB, lane, wid)};
+  tile_dma(kbase, ROWB, 0, Tk, ring, lane, wid, voff);
+  tile_dma(vbase, ROWB, 0, Tk, ring + TILE_BYTES, lane, wid, voff);
   if (nt > 1) {
-    tile_dma(kbase, D, TKV, Tk, ring + 2 * TILE_BYTES, lane, wid);
-    tile_dma(vbase, D, TKV, Tk, ring + 3 * TILE_BYTES, lane, wid);
+    tile_dma(kbase, ROWB, TKV, Tk, ring + 2 * TILE_BYTES, lane, wid, voff);
+    tile_dma(vbase, ROWB, TKV, Tk, ring + 3 * TILE_BYTES, lane, wid, voff);
   }
   // the wave's own Q rows: requested AFTER the DMA (one memory round trip for everything) and settled before the loop
 #pragma unroll
@@ -218,8 +269,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
     constexpr bool FAST = decltype(fast_)::value;
     if (t + 2 < nt) {
       const int sl = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
-      tile_dma(kbase, D, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid);
-      tile_dma(vbase, D, (t + 2) * TKV, Tk, ring + (2 * sl + 1) * TILE_BYTES, lane, wid);
+      tile_dma(kbase, ROWB, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid, voff);
+      tile_dma(vbase, ROWB, (t + 2) * TKV, Tk, ring + (2 * sl + 1) * TILE_BYTES, lane, wid, voff);
     }
     if (wave_active && FAST) {
       const char* kt = &lds[cur][0][0];
@@ -377,14 +428,14 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
       lse_v = m_[f] * scale + logf(l);
     }
     const int q = q0 + 16 * f + l15;
-    if (q < Tq) {
-      const float inv = 1.0f / l;
-      bf16* op = o + ((size_t)b * Tq + q) * (H * D) + h * D + 4 * lg;
+    const float inv = 1.0f / l;
 #pragma unroll
-      for (int df = 0; df < 4; ++df) store4<bf16>(op + df * 16, oacc[df][f] * inv);
-      if (lg == 0) lse[(size_t)bh * Tq + q] = lse_v;
-    }
+    for (int df = 0; df < 4; ++df) oacc[df][f] = oacc[df][f] * inv;
+    if (q < Tq && lg == 0) lse[(size_t)bh * Tq + q] = lse_v;
   }
+  if (wave_active)   // (the tile loop ended with a barrier: the ring is free, each wave takes 4 KiB of it as scratch)
+    store_tile32x64(oacc, &lds[0][0][0] + wid * 4096, o + ((size_t)b * Tq + q0) * (H * D) + h * D, (size_t)H * D, Tq - q0,
+                    lane);
 }
 
 // Fused backward of  x_hat = (sqk*c_q) * x/||x||  (reference model.py:108-112) in the epilogue of the attention
@@ -401,9 +452,23 @@ struct QkFuse {
 };
 
 __device__ __forceinline__ void qk_bwd_epilogue(f32x4 (&g)[4][2], const bf16* xh_bh, const QkFuse& fu, int row0, int T,
-                                                int H, int b, int h, int lane, int wid, float* red, int tile,
+                                                int H, int b, int h, int lane, int wid, char* lds0, int tile,
                                                 int ntile) {
+  // lds0: the (now idle) tile ring; bytes [4096*wid, +4096) = this wave's store scratch, [16384, +1024) = column sums
   const int l15 = lane & 15, lg = lane >> 4;
+  float* red = reinterpret_cast<float*>(lds0 + 16384);
+  // every global load of the epilogue goes out first (saved unit-direction rows, 1/norm, scale)
+  uint2 xr[2][4];
+  float rn[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    const int row = row0 + 16 * f + l15;
+    const int rc = row < T ? row : T - 1;
+#pragma unroll
+    for (int df = 0; df < 4; ++df)
+      xr[f][df] = *reinterpret_cast<const uint2*>(xh_bh + (size_t)rc * 64 + df * 16 + 4 * lg);
+    rn[f] = fu.rn[((size_t)b * T + rc) * H + h];
+  }
   f32x4 s[4], sinv[4], ds[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) {
@@ -412,30 +477,27 @@ __device__ __forceinline__ void qk_bwd_epilogue(f32x4 (&g)[4][2], const bf16* xh
 #pragma unroll
     for (int e = 0; e < 4; ++e) sinv[df][e] = s[df][e] != 0.f ? 1.0f / s[df][e] : 0.f;
   }
+  f32x4 outv[4][2];
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
-    const int row = row0 + 16 * f + l15;
-    const bool valid = row < T;
-    const int rc = valid ? row : T - 1;
+    const bool valid = row0 + 16 * f + l15 < T;
     f32x4 n[4], sg[4];
     float dot = 0.f;
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
-      n[df] = load4<bf16>(xh_bh + (size_t)rc * 64 + df * 16 + 4 * lg) * sinv[df];
+      const bf16x4 xb = __builtin_bit_cast(bf16x4, xr[f][df]);
+      n[df] = (f32x4){(float)xb[0], (float)xb[1], (float)xb[2], (float)xb[3]} * sinv[df];
       if (valid) ds[df] += g[df][f] * n[df];
       sg[df] = g[df][f] * s[df];
       dot += sg[df][0] * n[df][0] + sg[df][1] * n[df][1] + sg[df][2] * n[df][2] + sg[df][3] * n[df][3];
     }
     dot += __shfl_xor(dot, 16, 64);
     dot += __shfl_xor(dot, 32, 64);
-    if (valid) {
-      const size_t m = (size_t)b * T + row;
-      const float rn = fu.rn[m * H + h];
-      bf16* op = fu.out + m * fu.ld + h * 64 + 4 * lg;
 #pragma unroll
-      for (int df = 0; df < 4; ++df) store4<bf16>(op + df * 16, (sg[df] - n[df] * dot) * rn);
-    }
+    for (int df = 0; df < 4; ++df) outv[df][f] = (sg[df] - n[df] * dot) * rn[f];
   }
+  if (row0 < T)
+    store_tile32x64(outv, lds0 + wid * 4096, fu.out + ((size_t)b * T + row0) * fu.ld + h * 64, (size_t)fu.ld, T - row0, lane);
   // column sums over this workgroup's 128 rows: 16 lanes (l15) -> 4 waves -> one partial row
 #pragma unroll
   for (int df = 0; df < 4; ++df)
@@ -463,9 +525,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
                                                                 const bf16* __restrict__ og, float* __restrict__ delta,
                                                                 float scale, bf16* __restrict__ dqh, int H, int Tq,
                                                                 int Tk, QkFuse fu) {
-  // og != NULL: this kernel also produces delta[bh][q] = <dO_q, O_q> (the softmax-backward row term) from the attention
-  // output `og` (token-major like dout) and stores it for the dk/dv kernel, which runs after it; og == NULL: delta
-  // is an input.
+  // This kernel also produces delta[bh][q] = <dO_q, O_q> (the softmax-backward row term) from the attention output `og`
+  // (token-major like dout) and stores it, with lse in log2 units, in the [2,B,H,Tq] side buffer for the dk/dv kernel,
+  // which runs after it.  (og == NULL: delta is an input and no side buffer is written - not used by the launchers.)
   __shared__ __attribute__((aligned(16))) char lds[3][2][TILE_BYTES];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -483,11 +545,12 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
   // K/V ring: LDS-DMA two tiles ahead, counted vmcnt (4 younger DMA instructions may stay in flight); the prologue
   // DMA goes out first, the wave's own rows after it, and everything is settled before the tile loop (see settle())
   const unsigned ring = lds_addr(&lds[0][0][0]);
-  tile_dma(kbase, D, 0, Tk, ring, lane, wid);
-  tile_dma(vbase, D, 0, Tk, ring + TILE_BYTES, lane, wid);
+  const unsigned voff[TILE_DMA] = {tile_voff(0, ROWB, lane, wid), tile_voff(1, ROWB, lane, wid)};
+  tile_dma(kbase, ROWB, 0, Tk, ring, lane, wid, voff);
+  tile_dma(vbase, ROWB, 0, Tk, ring + TILE_BYTES, lane, wid, voff);
   if (nt > 1) {
-    tile_dma(kbase, D, TKV, Tk, ring + 2 * TILE_BYTES, lane, wid);
-    tile_dma(vbase, D, TKV, Tk, ring + 3 * TILE_BYTES, lane, wid);
+    tile_dma(kbase, ROWB, TKV, Tk, ring + 2 * TILE_BYTES, lane, wid, voff);
+    tile_dma(vbase, ROWB, TKV, Tk, ring + 3 * TILE_BYTES, lane, wid, voff);
   }
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
@@ -511,7 +574,11 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
       part += __shfl_xor(part, 16, 64);   // the row's 64 columns live on the 4 lanes l15 + 16*lg
       part += __shfl_xor(part, 32, 64);
       dl[f] = part;
-      if (lg == 0 && qu < Tq) delta[(size_t)bh * Tq + qu] = part;
+      if (lg == 0 && qu < Tq) {
+        // side buffer for the dk/dv kernel (runs after this one): delta, and lse already in log2 units
+        delta[(size_t)bh * Tq + qu] = part;
+        delta[((size_t)(gridDim.x / ((Tq + 127) / 128)) + bh) * Tq + qu] = lse2[f];
+      }
     } else {
       dl[f] = delta[(size_t)bh * Tq + q];
     }
@@ -546,8 +613,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
     constexpr bool MASKED = decltype(masked_)::value;
     if (t + 2 < nt) {
       const int sl = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
-      tile_dma(kbase, D, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid);
-      tile_dma(vbase, D, (t + 2) * TKV, Tk, ring + (2 * sl + 1) * TILE_BYTES, lane, wid);
+      tile_dma(kbase, ROWB, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid, voff);
+      tile_dma(vbase, ROWB, (t + 2) * TKV, Tk, ring + (2 * sl + 1) * TILE_BYTES, lane, wid, voff);
     }
     if (wave_active) {
       const char* kt = &lds[cur][0][0];
@@ -617,18 +684,10 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
 #pragma unroll
     for (int f = 0; f < 2; ++f) dq[i][f] = dq[i][f] * scale;
   if constexpr (FUSE) {
-    qk_bwd_epilogue(dq, qh + (size_t)bh * Tq * D, fu, q0, Tq, H, b, h, lane, wid, reinterpret_cast<float*>(&lds[0][0][0]),
-                    tile_, (Tq + 127) / 128);
+    qk_bwd_epilogue(dq, qh + (size_t)bh * Tq * D, fu, q0, Tq, H, b, h, lane, wid, &lds[0][0][0], tile_, (Tq + 127) / 128);
   } else {
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int q = q0 + 16 * f + l15;
-      if (q < Tq) {
-        bf16* op = dqh + ((size_t)bh * Tq + q) * D + 4 * lg;
-#pragma unroll
-        for (int df = 0; df < 4; ++df) store4<bf16>(op + df * 16, dq[df][f]);
-      }
-    }
+    if (wave_active)
+      store_tile32x64(dq, &lds[0][0][0] + wid * 4096, dqh + ((size_t)bh * Tq + q0) * D, (size_t)D, Tq - q0, lane);
   }
 }
 
@@ -643,11 +702,6 @@ __device__ __forceinline__ void glds4a(const void* gsrc, unsigned lds_off) {
       : "v"(gsrc), "s"(m)
       : "memory");
 }
-__device__ __forceinline__ uint2 pack4(const f32x4& a) {
-  bf16x4 v = {(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3]};
-  return __builtin_bit_cast(uint2, v);
-}
-
 // One workgroup = 4 waves x 32 keys; the 64-query tiles of Q and dO (+ their lse / delta rows) arrive by LDS-DMA into a
 // 3-slot ring two tiles ahead (counted vmcnt, one barrier per tile) - the same machine as the forward / dq kernels,
 // instead of the register-staged double buffer this kernel used before (which spilled at 3 waves per SIMD).
@@ -677,16 +731,19 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
   const int k0 = tile_ * 128 + wid * 32;
   const bf16* qbase = qh + (size_t)bh * Tq * D;
   const bf16* gbase = dout + (size_t)b * Tq * (H * D) + h * D;
-  const float* lbase = lse + (size_t)bh * Tq;
   const float* dbase = delta + (size_t)bh * Tq;
+  const float* lbase = delta + ((size_t)(gridDim.x / ((Tk + 127) / 128)) + bh) * Tq;   // lse * log2(e), written by the dq kernel
   const float c2 = scale * LOG2E;
   const int nt = (Tq + TKV - 1) / TKV;
   const unsigned ring = lds_addr(&lds[0]);
 
+  const unsigned ldg_bytes = (unsigned)(H * D * 2);
+  const unsigned voff_q[TILE_DMA] = {tile_voff(0, ROWB, lane, wid), tile_voff(1, ROWB, lane, wid)};
+  const unsigned voff_g[TILE_DMA] = {tile_voff(0, ldg_bytes, lane, wid), tile_voff(1, ldg_bytes, lane, wid)};
   auto tile_issue = [&](int t, int slot) {
     const unsigned so = ring + (unsigned)slot * DKV_SLOT;
-    tile_dma(qbase, D, t * TKV, Tq, so, lane, wid);
-    tile_dma(gbase, (size_t)H * D, t * TKV, Tq, so + TILE_BYTES, lane, wid);
+    tile_dma(qbase, ROWB, t * TKV, Tq, so, lane, wid, voff_q);
+    tile_dma(gbase, ldg_bytes, t * TKV, Tq, so + TILE_BYTES, lane, wid, voff_g);
     int q = t * TKV + lane;
     q = q < Tq ? q : Tq - 1;
     glds4a(lbase + q, so + 2 * TILE_BYTES);        // every wave writes the same 256 bytes (keeps vmcnt uniform)
@@ -745,16 +802,16 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
           if (!MASKED || qfi < nqf) {
             const uint4 a0 = row_frag(qt, qfi * 16, 0, l15, lg), a1 = row_frag(qt, qfi * 16, 1, l15, lg);
             const uint4 g0 = row_frag(gt, qfi * 16, 0, l15, lg), g1 = row_frag(gt, qfi * 16, 1, l15, lg);
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(st + qfi * 16 + 4 * lg) * LOG2E;
-            const f32x4 d4 = *reinterpret_cast<const f32x4*>(st + 64 + qfi * 16 + 4 * lg);
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(st + qfi * 16 + 4 * lg);
+            f32x4 nd4 = -*reinterpret_cast<const f32x4*>(st + 64 + qfi * 16 + 4 * lg);
+            asm volatile("" : "+v"(nd4));   // one register quad, read as the C operand of both key fragments' chains
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
               f32x4 z = {0.f, 0.f, 0.f, 0.f};
               z = mfma16(a0, kf_[f][0], z);
               z = mfma16(a1, kf_[f][1], z);  // S[q][key]
-              f32x4 w = -d4;                 // row constants as the initial accumulator
-              w = mfma16(g0, vf_[f][0], w);
-              w = mfma16(g1, vf_[f][1], w);  // dP[q][key] - delta[q]
+              f32x4 w = mfma16(g0, vf_[f][0], nd4);   // row constants -delta as the initial accumulator
+              w = mfma16(g1, vf_[f][1], w);           // dP[q][key] - delta[q]
               f32x4 p, dsv;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
@@ -804,31 +861,17 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int f = 0; f < 2; ++f) dk[i][f] = dk[i][f] * scale;
+  char* scr = &lds[0] + wid * 4096;   // (the tile loop ended with a barrier: the ring is free)
   if constexpr (FUSE) {
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int k = k0 + 16 * f + l15;
-      if (k < Tk) {
-        bf16* vp = fu.out_v + ((size_t)b * Tk + k) * fu.ld + h * 64 + 4 * lg;
-#pragma unroll
-        for (int df = 0; df < 4; ++df) store4<bf16>(vp + df * 16, dv[df][f]);
-      }
-    }
-    qk_bwd_epilogue(dk, kh + (size_t)bh * Tk * D, fu, k0, Tk, H, b, h, lane, wid, reinterpret_cast<float*>(&lds[0]),
-                    tile_, (Tk + 127) / 128);
+    if (wave_active)
+      store_tile32x64(dv, scr, fu.out_v + ((size_t)b * Tk + k0) * fu.ld + h * 64, (size_t)fu.ld, Tk - k0, lane);
+    __builtin_amdgcn_wave_barrier();
+    qk_bwd_epilogue(dk, kh + (size_t)bh * Tk * D, fu, k0, Tk, H, b, h, lane, wid, &lds[0], tile_, (Tk + 127) / 128);
   } else {
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int k = k0 + 16 * f + l15;
-      if (k < Tk) {
-        bf16* kp = dkh + ((size_t)bh * Tk + k) * D + 4 * lg;
-        bf16* vp = dvh + ((size_t)bh * Tk + k) * D + 4 * lg;
-#pragma unroll
-        for (int df = 0; df < 4; ++df) {
-          store4<bf16>(kp + df * 16, dk[df][f]);
-          store4<bf16>(vp + df * 16, dv[df][f]);
-        }
-      }
+    if (wave_active) {
+      store_tile32x64(dk, scr, dkh + ((size_t)bh * Tk + k0) * D, (size_t)D, Tk - k0, lane);
+      __builtin_amdgcn_wave_barrier();
+      store_tile32x64(dv, scr, dvh + ((size_t)bh * Tk + k0) * D, (size_t)D, Tk - k0, lane);
     }
   }
 }
@@ -849,6 +892,7 @@ int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const v
                        float* delta, float scale, void* dqh, void* dkh, void* dvh, int B, int H, int Tq, int Tk,
                        int d, hipStream_t s) {
   NVIT_REQUIRE(d == 64, "attn_bwd: the MFMA kernel supports head dim 64 only (got %d)", d);
+  NVIT_REQUIRE(o != nullptr && delta != nullptr, "attn_bwd: the attention output and the [2,B,H,Tq] side buffer are required");
   dim3 gq((unsigned)(cdiv(Tq, 128) * B * H)), gk((unsigned)(cdiv(Tk, 128) * B * H));
   QkFuse none{};
   hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, gq, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
@@ -868,6 +912,7 @@ int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, c
                              int H, int Tq, int Tk, int d, hipStream_t s) {
   NVIT_REQUIRE(d == 64, "attn_bwd: the MFMA kernel supports head dim 64 only (got %d)", d);
   NVIT_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0, "attn_bwd: leading dims must be multiples of 4");
+  NVIT_REQUIRE(o != nullptr && delta != nullptr, "attn_bwd: the attention output and the [2,B,H,Tq] side buffer are required");
   dim3 gq((unsigned)(cdiv(Tq, 128) * B * H)), gk((unsigned)(cdiv(Tk, 128) * B * H));
   QkFuse fq{rq, sqk, c_q, (bf16*)dq, nullptr, ldq, part_q};
   QkFuse fk{rk, sqk, c_q, (bf16*)dk, (bf16*)dv, ldkv, part_k};
