@@ -137,9 +137,10 @@ int nvit_set_gemm_sched(int dynamic);
  * 1 = persistent 256-row kernels for large problems (default), 2 = persistent kernels whatever the tile count;
  * tn_impl: 0 = 128x128 kernel only, 1 = persistent 256x256 kernel for eligible shapes (default). */
 int nvit_set_gemm_impl(int nt_impl, int tn_impl);
-/* Work-item deal of the persistent weight-gradient kernel: 1 = XCD-contiguous (default: tiles that share operand
- * panels run on one XCD and hit its L2), 0 = round-robin (kept for A/B measurements; NVIT_TN_ORDER=0). */
-int nvit_set_tn_order(int xcd_contiguous);
+/* Variants of the persistent weight-gradient kernel (A/B measurements).  bit 0: 1 = XCD-contiguous work-item deal
+ * (default: tiles that share operand panels run on one XCD and hit its L2), 0 = round-robin (NVIT_TN_ORDER=0);
+ * +2 = ring of 4 x 32 KiB stages, +4 = ring of 2 x 64 KiB stages (default; NVIT_TN_RING=4 selects the former). */
+int nvit_set_tn_order(int mode);
 int nvit_gemm_nt_fusable(int dt, int M, int N, int K);
 int nvit_gemm_nt_swiglu_bwd(int dt, const void* A, int lda, const void* B, int ldb, const void* uv, void* duv,
                             float* part, int M, int F, int K, const float* gs, float gscale, void* stream);

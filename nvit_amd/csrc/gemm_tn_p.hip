@@ -3,8 +3,13 @@
 // Same machine as gemm_p.hip, turned for the "both operands are reduction-major" case:
 //   * output tile 256 (n) x 256 (k'), 8 waves (2 x 4: 128 k' x 64 n each), one workgroup per CU;
 //   * work items = (output tile, row split); a workgroup walks its items persistently, the LDS-DMA
-//     stream (2-slot ring of 64 KiB stages = 64 reduction rows of both operands) is continuous
-//     across items;
+//     stream is continuous across items.  Ring (template DEEP): 2 slots of 64 KiB stages (64 reduction rows of
+//     both operands; default), or 4 slots of 32 KiB with three stages in flight behind a counted vmcnt
+//     (NVIT_TN_RING=4).  vmcnt retires in order, so the look-ahead a wave can have IS the ring depth; the deeper
+//     ring was built to test whether the 28 % of wave cycles this kernel spends in s_waitcnt/barrier (PMC) is memory
+//     latency - it is not: at the same 128 KiB the 4-slot ring is 2 % SLOWER on the four block shapes
+//     (tools/tn_ab.py, interleaved rounds), i.e. the operands arrive in time and the extra barrier per 32 rows costs
+//     more than the look-ahead buys;
 //   * tiles are stored in LDS exactly as they sit in memory ([m][col], 512-byte rows, 16-byte chunks
 //     XOR-swizzled by the row so that the transposed reads are conflict free) and the MFMA operands
 //     are fetched with ds_read_b64_tr_b16 (hardware 4x16 transpose); fp32 uses ds_read_b32;
@@ -16,9 +21,7 @@
 namespace {
 
 constexpr int TBN = 256, TBK = 256;
-constexpr int OP_BYTES = 32768;           // one operand stage: 64 rows x 512 B (bf16) or 32 rows x 1 KiB (fp32)
-constexpr int TSLOT_BYTES = 2 * OP_BYTES;  // 64 KiB
-constexpr int TN_LDS = 2 * TSLOT_BYTES;    // 128 KiB
+constexpr int TN_LDS = 131072;             // 128 KiB ring: 2 x 64 KiB or 4 x 32 KiB stages
 
 struct TnpArgs {
   const char* A;
@@ -34,11 +37,17 @@ struct TnpArgs {
 
 __device__ __forceinline__ int tnp_swz(int m) { return (((m & 3) | (((m >> 3) & 1) << 2)) << 1); }
 
-template <typename T>
+template <typename T, int DEEP>
 __global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int RB = sizeof(T) == 2 ? 64 : 32;       // reduction rows per stage
+  constexpr int NSLOT = DEEP ? 4 : 2;
+  constexpr int TSLOT_BYTES = TN_LDS / NSLOT;        // 64 / 32 KiB
+  constexpr int OP_BYTES = TSLOT_BYTES / 2;          // one operand stage
   constexpr int ROW_BYTES = 256 * sizeof(T);         // 512 / 1024
+  constexpr int RB = OP_BYTES / ROW_BYTES;           // reduction rows per stage: bf16 64 / 32, fp32 32 / 16
+  constexpr int ODMA = OP_BYTES / 8192;              // DMA wave-instructions per operand per wave per stage: 4 / 2
+  constexpr int DPS = 2 * ODMA;                      // ... per stage
+  constexpr int KS = RB * (int)sizeof(T) / 64;       // MFMA k-steps per stage (32 bf16 / 16 fp32 rows each): 2 / 1
   constexpr int CHUNKS = ROW_BYTES / 16;             // 32 / 64
   constexpr int RPI = 1024 / ROW_BYTES;              // rows per DMA wave-instruction: 2 / 1
   constexpr int EPC = 16 / sizeof(T);
@@ -85,9 +94,9 @@ __global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
   };
 
   // ---- load cursor
-  const char* abase[4];
-  const char* bbase[4];
-  int srow[4];
+  const char* abase[ODMA];
+  const char* bbase[ODMA];
+  int srow[ODMA];
   int l_it = 0, l_t = 0, l_nt = 0, l_mbeg = 0, l_mend = 0, l_slot = 0;
   size_t astep = (size_t)RB * g.lda * sizeof(T), bstep = (size_t)RB * g.ldb * sizeof(T);
   auto set_load_item = [&](int it) {
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
     const int rows = l_mend - l_mbeg;
     l_nt = rows > 0 ? (rows + RB - 1) / RB : 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ODMA; ++i) {
       srow[i] = (i * 8 + wid) * RPI + lrow;
       int ch;
       if constexpr (sizeof(T) == 2)
@@ -116,14 +125,14 @@ __global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
   auto issue_stage = [&]() {
     const unsigned bo = lds_base + wave_off + (unsigned)l_slot * TSLOT_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ODMA; ++i) {
       const bool mok = (l_mbeg + l_t * RB + srow[i]) < l_mend;
       const char* pa = mok ? abase[i] + (size_t)l_t * astep : zsrc;
       const char* pb = mok ? bbase[i] + (size_t)l_t * bstep : zsrc;
       glds16(pa, bo + i * 8192);
       glds16(pb, bo + OP_BYTES + i * 8192);
     }
-    l_slot ^= 1;
+    l_slot = l_slot == NSLOT - 1 ? 0 : l_slot + 1;
     if (++l_t == l_nt) {
       l_t = 0;
       ++l_it;
@@ -172,13 +181,21 @@ __global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
 
   set_load_item(0);
   advance_to_nonempty();
-  issue_stage();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // prologue: NSLOT-1 stages in flight, stage 0 landed
+  int issued = 0;
+  for (; issued < NSLOT - 1 && issued < total_stages; ++issued) issue_stage();
+  if (issued >= 3)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPS) : "memory");
+  else if (issued == 2)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS) : "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   int slot = 0;
   for (int s = 0; s < total_stages; ++s) {
-    if (s + 1 < total_stages) issue_stage();  // DMA(s+1) into the other slot (vacated by stage s-1)
+    // DMA(s+NSLOT-1) into the slot vacated by stage s-1 (every wave passed the barrier that ended it)
+    if (s + NSLOT - 1 < total_stages) issue_stage();
     const char* la = smem + slot * TSLOT_BYTES;  // A tile: [m][n]  -> MFMA B operand (cols = n)
     const char* lb = la + OP_BYTES;              // B tile: [m][k'] -> MFMA A operand (rows = k')
     if constexpr (sizeof(T) == 2) {
@@ -186,7 +203,7 @@ __global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
       // B tile against the four n fragments of the A tile); every ds_read_b64_tr_b16 pair is written in
       // consumption order and sched_group_barrier pins "4 MFMAs, then the reads needed ~3 steps later".
       const int q = l15 >> 2, p = l15 & 3;
-      uint4 fa[2][4], fb[2][8];
+      uint4 fa[KS][4], fb[KS][8];
 #define TRF(dst_, base_, ks_, col0_)                                                                              \
   {                                                                                                               \
     const int mrow = (ks_) * 32 + lg * 8 + q;                                                                     \
@@ -201,26 +218,40 @@ __global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
 #define FA(ks_, j_) TRF(fa[ks_][j_], la, ks_, wc * 64 + (j_) * 16)
 #define FB(ks_, i_) TRF(fb[ks_][i_], lb, ks_, wr * 128 + (i_) * 16)
       __builtin_amdgcn_sched_barrier(0);
-      FA(0, 0) FA(0, 1) FA(0, 2) FA(0, 3) FB(0, 0) FB(0, 1) FB(0, 2)
-      FB(0, 3)
-      FB(0, 4) FA(1, 0) FB(0, 5) FA(1, 1) FB(0, 6) FA(1, 2) FB(0, 7) FA(1, 3)
-      FB(1, 0) FB(1, 1) FB(1, 2) FB(1, 3) FB(1, 4) FB(1, 5) FB(1, 6) FB(1, 7)
+      if constexpr (KS == 2) {
+        FA(0, 0) FA(0, 1) FA(0, 2) FA(0, 3) FB(0, 0) FB(0, 1) FB(0, 2)
+        FB(0, 3)
+        FB(0, 4) FA(1, 0) FB(0, 5) FA(1, 1) FB(0, 6) FA(1, 2) FB(0, 7) FA(1, 3)
+        FB(1, 0) FB(1, 1) FB(1, 2) FB(1, 3) FB(1, 4) FB(1, 5) FB(1, 6) FB(1, 7)
+      } else {
+        FA(0, 0) FA(0, 1) FA(0, 2) FA(0, 3) FB(0, 0) FB(0, 1) FB(0, 2)
+        FB(0, 3) FB(0, 4) FB(0, 5) FB(0, 6) FB(0, 7)
+      }
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
+      for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) Mma<bf16>::run(fb[ks][i], fa[ks][j], acc[i][j]);
       __builtin_amdgcn_sched_group_barrier(0x100, 14, 0);
+      if constexpr (KS == 2) {
 #pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
-        if (t == 0)
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        else if (t < 5)
-          __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-        else if (t < 13)
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        for (int t = 0; t < 16; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+          if (t == 0)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          else if (t < 5)
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          else if (t < 13)
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+      } else {
+        // 8 steps of 4 MFMAs; the 5 fragments (10 reads) not yet requested follow the first five steps
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+          if (t < 5) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
 #undef FA
@@ -244,8 +275,10 @@ __global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[i], fa[j], acc[i][j], 0, 0, 0);
       }
     }
+    bool stored = false;
     if (++c_t == c_nt) {
       store_item(c_it);
+      stored = true;
       ++c_it;
       c_t = 0;
       c_nt = c_it < my_items ? stages_of(c_it) : 0;
@@ -255,18 +288,29 @@ __global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
         c_nt = c_it < my_items ? stages_of(c_it) : 0;
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA(s+1) landed (and any slab stores drained)
+    // retire DMA(s+1); the stages issued after it stay in flight.  (After an item's slab stores - younger than every
+    // DMA in the queue - drain everything: once per item.)
+    const int ahead = total_stages - 1 - (s + 1);   // stages issued beyond s+1 that exist
+    if (stored || NSLOT == 2 || ahead <= 0)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (ahead == 1)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPS) : "memory");
     __syncthreads();
-    slot ^= 1;
+    slot = slot == NSLOT - 1 ? 0 : slot + 1;
   }
 }
 
 }  // namespace
 
-// item deal of the persistent weight-gradient kernel: 1 = XCD-contiguous (default), 0 = round-robin (A/B measurements)
-static int g_tn_order = -1;
-extern "C" int nvit_set_tn_order(int xcd_contiguous) {
-  g_tn_order = xcd_contiguous ? 1 : 0;
+// item deal of the persistent weight-gradient kernel: 1 = XCD-contiguous (default), 0 = round-robin (A/B measurements);
+// bits 1/2 of the argument select the ring: +2 = 4 x 32 KiB slots, +4 = 2 x 64 KiB slots (default)
+static int g_tn_order = -1, g_tn_deep = -1;
+extern "C" int nvit_set_tn_order(int mode) {
+  g_tn_order = (mode & 1) ? 1 : 0;
+  if (mode & 2) g_tn_deep = 1;
+  if (mode & 4) g_tn_deep = 0;
   return NVIT_OK;
 }
 
@@ -282,15 +326,16 @@ int nvit_gemm_tn_persistent_launch(int dt, const void* A, int lda, const void* B
       NVIT_FAIL(NVIT_EINVAL, "gemm_tn: cannot query device properties");
     n_cu = prop.multiProcessorCount;
   }
-  static bool attr_set[2] = {false, false};
+  if (g_tn_deep < 0) g_tn_deep = getenv("NVIT_TN_RING") ? (atoi(getenv("NVIT_TN_RING")) == 4) : 0;   // measured (tools/tn_ab.py): the deeper ring is 2 % slower
+  const int deep = g_tn_deep;
+  static bool attr_set[2][2] = {{false, false}, {false, false}};
   const int idx = dt == NVIT_BF16 ? 1 : 0;
-  if (!attr_set[idx]) {
-    hipError_t e = dt == NVIT_BF16 ? hipFuncSetAttribute((const void*)gemm_tn_persistent_kernel<bf16>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS)
-                                   : hipFuncSetAttribute((const void*)gemm_tn_persistent_kernel<float>,
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS);
+  if (!attr_set[idx][deep]) {
+    const void* fn = dt == NVIT_BF16 ? (deep ? (const void*)gemm_tn_persistent_kernel<bf16, 1> : (const void*)gemm_tn_persistent_kernel<bf16, 0>)
+                                     : (deep ? (const void*)gemm_tn_persistent_kernel<float, 1> : (const void*)gemm_tn_persistent_kernel<float, 0>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, TN_LDS);
     if (e != hipSuccess) NVIT_FAIL((int)e, "gemm_tn: cannot raise LDS limit: %s", hipGetErrorString(e));
-    attr_set[idx] = true;
+    attr_set[idx][deep] = true;
   }
   TnpArgs g;
   g.A = (const char*)A;
@@ -303,7 +348,7 @@ int nvit_gemm_tn_persistent_launch(int dt, const void* A, int lda, const void* B
   g.lda = lda;
   g.ldb = ldb;
   g.splits = splits;
-  const int rb = dt == NVIT_BF16 ? 64 : 32;
+  const int rb = dt == NVIT_BF16 ? 64 : 32;   // row-split granularity (a multiple of both ring variants' stage rows)
   int rps = cdiv(Mred, splits);
   rps = cdiv(rps, rb) * rb;
   g.rows_per_split = rps;
@@ -313,10 +358,17 @@ int nvit_gemm_tn_persistent_launch(int dt, const void* A, int lda, const void* B
   g.xcd_order = g_tn_order;
   const int nitems = g.tiles_n * g.tiles_k * splits;
   const int grid = nitems < n_cu ? nitems : n_cu;
-  if (dt == NVIT_BF16)
-    hipLaunchKernelGGL(gemm_tn_persistent_kernel<bf16>, dim3(grid), dim3(512), TN_LDS, s, g);
-  else
-    hipLaunchKernelGGL(gemm_tn_persistent_kernel<float>, dim3(grid), dim3(512), TN_LDS, s, g);
+  if (dt == NVIT_BF16) {
+    if (deep)
+      hipLaunchKernelGGL((gemm_tn_persistent_kernel<bf16, 1>), dim3(grid), dim3(512), TN_LDS, s, g);
+    else
+      hipLaunchKernelGGL((gemm_tn_persistent_kernel<bf16, 0>), dim3(grid), dim3(512), TN_LDS, s, g);
+  } else {
+    if (deep)
+      hipLaunchKernelGGL((gemm_tn_persistent_kernel<float, 1>), dim3(grid), dim3(512), TN_LDS, s, g);
+    else
+      hipLaunchKernelGGL((gemm_tn_persistent_kernel<float, 0>), dim3(grid), dim3(512), TN_LDS, s, g);
+  }
   NVIT_CHECK_LAUNCH("gemm_tn_persistent");
   return NVIT_OK;
 }

@@ -1,5 +1,6 @@
-"""A/B of the weight-gradient GEMM item deal (round-robin vs XCD-contiguous) on the four block shapes of Base B=128,
-interleaved rounds in one process (guide rule 24).  python tools/tn_ab.py"""
+"""A/B of the weight-gradient GEMM variants on the four block shapes of Base B=128, interleaved rounds in one process
+(guide rule 24): mode 5 = XCD-contiguous items + 2 x 64 KiB ring (round-1 ring), mode 3 = XCD-contiguous + 4 x 32 KiB
+ring, mode 4 = round-robin items + 2 x 64 KiB ring (round 1).  python tools/tn_ab.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,8 +17,9 @@ for name, N, K, perm in shapes:
     bufs[name] = (A, B, G)
 lib = _lib.load()
 res = {}
+MODES = (4, 5, 3)
 for rnd in range(6):
-    for order in (0, 1):
+    for order in MODES:
         lib.nvit_set_tn_order(order)
         for name, N, K, perm in shapes:
             A, B, G = bufs[name]
@@ -30,14 +32,14 @@ for rnd in range(6):
             e1.record()
             torch.cuda.synchronize()
             res.setdefault((name, order), []).append(e0.elapsed_time(e1) / 5)
-lib.nvit_set_tn_order(1)
-tot = {0: 0.0, 1: 0.0}
+lib.nvit_set_tn_order(3)
+tot = {m: 0.0 for m in MODES}
 for name, N, K, perm in shapes:
     fl = 2.0 * M * N * K
-    for order in (0, 1):
+    for order in MODES:
         t = sorted(res[(name, order)])
         med = t[len(t) // 2]
         tot[order] += med
-        print(f"{name:4s} N={N:5d} K={K:5d} order={order}: median {med * 1e3:8.1f} us  min {t[0] * 1e3:8.1f} us  "
+        print(f"{name:4s} N={N:5d} K={K:5d} mode={order}: median {med * 1e3:8.1f} us  min {t[0] * 1e3:8.1f} us  "
               f"{fl / med / 1e9:7.1f} TF/s  (splits {ops.tn_splits(M, N, K, 1)})")
-print(f"per block: round-robin {tot[0]:.3f} ms, xcd-contiguous {tot[1]:.3f} ms  -> x12 = {12 * tot[0]:.2f} vs {12 * tot[1]:.2f} ms/step")
+print("per block [ms]: " + ", ".join(f"mode {m}: {tot[m]:.3f} (x12 = {12 * tot[m]:.2f})" for m in MODES))
