@@ -213,6 +213,11 @@ int nvit_colsum_reduce(const float* part, int nblk, int N, float* out, int accum
 int nvit_colsum(const void* a, int a_dt, int lda, const void* b, int b_dt, int ldb, int R, int N, int period,
                 float* out, int accumulate, float scale, void* stream);
 int nvit_cast(const float* src, void* dst, int dt, int64_t n, void* stream);
+/* Input pipeline, deterministic part (train.py:1084-1090): ToTensor + kornia Normalize(mean, std) in one pass.
+ * in: uint8 [B,H,W,C] (in_is_u8_hwc = 1; scaled by 1/255 first) or fp32 [B,C,H,W] already in [0,1]; out fp32 [B,C,H,W]
+ * = (in - mean) / std.  (The reference's randomised AutoAugment policy is third-party kornia code: not rebuilt.) */
+int nvit_normalize_images(const void* in, int in_is_u8_hwc, float* out, int B, int C, int H, int W, float mean, float std_,
+                          void* stream);
 /* out[r,n] = a[r,n] * s[n] * c   (sz scaling model.py:466-468 and its backward) */
 int nvit_scale_cols(const float* a, int lda, const float* s, float c, void* out, int out_dt, int ldo, int R, int N,
                     void* stream);

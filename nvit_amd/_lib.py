@@ -53,6 +53,7 @@ SIGNATURES = {
     "nvit_colsum_reduce": [_vp, _i, _i, _vp, _i, _i, _vp, _f, _vp],
     "nvit_colsum": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _f, _vp],
     "nvit_cast": [_vp, _vp, _i, _i64, _vp],
+    "nvit_normalize_images": [_vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp],
     "nvit_scale_cols": [_vp, _i, _vp, _f, _vp, _i, _i, _i, _i, _vp],
     "nvit_attn_fwd": [_i, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_attn_fwd_bounded": [_i, _i, _vp, _vp, _vp, _f, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -532,6 +532,30 @@ __global__ void scale_cols_kernel(const float* a, int lda, const float* s, float
   st1<T>(out + (size_t)r * ldo + n, a[(size_t)r * lda + n] * s[n] * c);
 }
 
+// Input pipeline, deterministic part (reference train.py:1084-1090): ToTensor (uint8 HWC -> float CHW in [0,1]) and
+// kornia Normalize(mean 0.5, std 0.5) in one pass: out[b,c,y,x] = (in/255 - mean) / std.  IN = uint8 (HWC, one byte per
+// channel) or float (CHW, already in [0,1]).  Four output pixels per thread, 16-byte stores.
+template <typename IN>
+__global__ void normalize_images_kernel(const IN* in, float* out, int B, int C, int H, int W, float mean, float inv_std) {
+  const long long n4 = (long long)B * C * H * (W / 4);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int x4 = (int)(i % (W / 4)) * 4;
+    long long r = i / (W / 4);
+    const int y = (int)(r % H);
+    r /= H;
+    const int c = (int)(r % C), b = (int)(r / C);
+    f32x4 v;
+    if constexpr (sizeof(IN) == 1) {
+      const IN* p = in + (((size_t)b * H + y) * W + x4) * C + c;   // HWC
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (float)p[(size_t)e * C] * (1.0f / 255.0f);
+    } else {
+      v = *reinterpret_cast<const f32x4*>(in + (((size_t)b * C + c) * H + y) * W + x4);
+    }
+    *reinterpret_cast<f32x4*>(out + (((size_t)b * C + c) * H + y) * W + x4) = (v - mean) * inv_std;
+  }
+}
+
 int row_grid(int M) {
   int blocks = cdiv(M, ROW_WAVES);
   return blocks > 2048 ? 2048 : blocks;
@@ -735,6 +759,27 @@ extern "C" int nvit_cast(const float* src, void* dst, int dt, int64_t n, void* s
   else
     hipLaunchKernelGGL(cast_kernel<bf16>, dim3(blocks), dim3(256), 0, s, src, (bf16*)dst, n4);
   NVIT_CHECK_LAUNCH("cast");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_normalize_images(const void* in, int in_is_u8_hwc, float* out, int B, int C, int H, int W, float mean,
+                                     float std_, void* stream) {
+  NVIT_REQUIRE(in && out && B > 0 && C > 0 && H > 0 && W > 0 && W % 4 == 0 && std_ != 0.f,
+               "normalize_images: bad arguments (W must be a multiple of 4)");
+  NVIT_REQUIRE(((uintptr_t)out & 15) == 0 && (in_is_u8_hwc || ((uintptr_t)in & 15) == 0),
+               "normalize_images: pointers must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const long long n4 = (long long)B * C * H * (W / 4);
+  int blocks = cdiv(n4, 256);
+  if (blocks > 8192) blocks = 8192;
+  ProfScope ps(NVIT_KID_PATCHIFY, 0.0, (double)n4 * 4.0 * (in_is_u8_hwc ? 5.0 : 8.0), s);
+  if (in_is_u8_hwc)
+    hipLaunchKernelGGL(normalize_images_kernel<unsigned char>, dim3(blocks), dim3(256), 0, s, (const unsigned char*)in, out,
+                       B, C, H, W, mean, 1.0f / std_);
+  else
+    hipLaunchKernelGGL(normalize_images_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)in, out, B, C, H, W,
+                       mean, 1.0f / std_);
+  NVIT_CHECK_LAUNCH("normalize_images");
   return NVIT_OK;
 }
 

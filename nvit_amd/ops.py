@@ -301,6 +301,24 @@ def cast(src: Tensor, dt: int) -> Tensor:
     return dst
 
 
+def normalize_images(x: Tensor, mean: float = 0.5, std: float = 0.5) -> Tensor:
+    """ToTensor + Normalize(mean, std) on the device (reference train.py:1084-1090, the deterministic part of its input
+    pipeline): uint8 [B,H,W,C] (scaled by 1/255) or fp32 [B,C,H,W] in [0,1] -> fp32 [B,C,H,W]."""
+    _chk_dev(x)
+    x = x.contiguous()
+    if x.dtype == torch.uint8:
+        B, H, W, Cc = x.shape
+        u8 = 1
+    elif x.dtype == torch.float32:
+        B, Cc, H, W = x.shape
+        u8 = 0
+    else:
+        raise TypeError("normalize_images: uint8 [B,H,W,C] or float32 [B,C,H,W]")
+    out = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
+    check(_lib.load().nvit_normalize_images(_p(x), u8, _p(out), B, Cc, H, W, mean, std, _s()), "nvit_normalize_images")
+    return out
+
+
 def scale_cols(a: Tensor, s: Tensor, c: float, R: int, N: int, out: Tensor, lda: Optional[int] = None,
                ldo: Optional[int] = None) -> Tensor:
     lda = a.stride(0) if lda is None else lda

@@ -88,3 +88,19 @@ def test_public_helpers_present():
     for loc in ([0, 0], [1, 2], [3, 3]):
         assert torch.equal(km.get_neighborhood_distances(torch.tensor(loc)),
                            O.som_neighborhood_d2(torch.tensor(loc), km.m, km.n))
+
+
+def test_reference_import_lines_resolve_to_this_implementation():
+    """`from nvit.model import ViT, ViTConfig` (reference train.py:37) and `from nvit.kohonen import KohonenMap`
+    (reference model.py:10) work unchanged and give the nvit_amd classes (nvit/ is an import shim)."""
+    import importlib
+    m = importlib.import_module("nvit.model")
+    k = importlib.import_module("nvit.kohonen")
+    from nvit_amd import model as M
+    from nvit_amd.config import ViTConfig
+    from nvit_amd.kohonen import KohonenMap
+    assert m.ViT is M.ViT and m.ViTConfig is ViTConfig and m.Block is M.Block
+    assert m.CrossAttentionBlock is M.CrossAttentionBlock and m.RMSNorm is M.RMSNorm and m.justnorm is M.justnorm
+    assert k.KohonenMap is KohonenMap
+    import nvit
+    assert len(list(nvit.__path__)) >= 1

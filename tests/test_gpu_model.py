@@ -572,3 +572,54 @@ def test_large_config_full_size_vs_cpu_oracle():
     blk = m.transformer.h[-1]
     assert (blk.c_fc.weight.detach().norm(dim=1) - 1).abs().max().item() < 1e-5
     assert (blk.mlp_c_proj.weight.detach().norm(dim=0) - 1).abs().max().item() < 1e-5
+
+
+def test_base_kohonen_config_c5_vs_cpu_oracle():
+    """BASELINE config C5 (nViT-Base + Kohonen head, 2 maps of 16x16 nodes, C=768, T=784) at full model size, B=2:
+    fp32 mode against the oracle - logits, the four aux losses, the reconstruction loss, the SOM nodes after the
+    in-forward update, every gradient incl. the node gradients; bf16 mode against both oracles."""
+    from nvit_amd.train import total_loss
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    cfg = named_config("base_k")
+    X, y = synthetic_batch(cfg, 2)
+    p = O.make_params(formula_state_dict(cfg))
+    O.renorm_(p, cfg)
+    l32, loss32, aux32 = O.loss_and_grads(p, cfg, X, y, step=1, want_aux=True)
+    m = build(cfg, "fp32", True).train()
+    logits, aux = m(X.cuda())
+    loss = total_loss(cfg, logits, aux, y.cuda())
+    loss.backward()
+    e = (logits.detach().cpu() - l32).abs().max().item()
+    print(f"[base_k B=2] fp32 mode: max|dlogit| {e:.3e} (|logit|max {l32.abs().max().item():.3f}), loss {loss.item():.6f} "
+          f"vs {loss32.item():.6f}")
+    assert e < 2e-5
+    assert abs(loss.item() - loss32.item()) < 2e-5 * max(1.0, abs(loss32.item()))
+    for k in ("kohonen_consistency", "kohonen_smoothness", "local_quantization", "global_quantization", "reconstruction"):
+        assert abs(aux[k].item() - aux32[k].item()) < 2e-5 * max(1.0, abs(aux32[k].item())), k
+    for mod, key in ((m.local_kohonen, "local_kohonen.nodes"), (m.global_kohonen, "global_kohonen.nodes")):
+        assert (mod.nodes.detach().cpu() - p[key].detach()).abs().max().item() < 5e-6, key
+    worst = 0.0
+    for n, q in m.named_parameters():
+        if q.grad is None or p[n].grad is None:
+            continue
+        ref = p[n].grad
+        err, s = (q.grad.cpu() - ref).abs().max().item(), ref.abs().max().item()
+        worst = max(worst, err / (s + 1e-12))
+        assert err <= 5e-4 * s + 1e-8, (n, err, s)
+    print(f"   fp32 mode: worst relative gradient error {worst:.3e}")
+    # bf16 mode (fresh weights: the SOM nodes were updated in place by the forward above)
+    pe = O.make_params(formula_state_dict(cfg))
+    O.renorm_(pe, cfg)
+    lem, _, _ = O.loss_and_grads(pe, cfg, X, y, lowp=O.bf16_round, step=1, want_aux=True)
+    mb = build(cfg, "bf16", True).train()
+    with torch.no_grad():
+        lb, auxb = mb(X.cuda())
+    e32, eem = (lb.cpu() - l32).abs().max().item(), (lb.cpu() - lem).abs().max().item()
+    d_emu = (lem - l32).abs().max().item()
+    lmax = l32.abs().max().item()
+    print(f"   bf16 mode: max|dlogit| vs bf16-operand oracle {eem:.3e}, vs fp32 oracle {e32:.3e}; oracle bf16-operand vs fp32 "
+          f"{d_emu:.3e}")
+    # (the Kohonen branch feeds un-normalised node vectors, |repr| ~ sqrt(C) = 28, through three cross-attention calls:
+    #  its operand-rounding noise is larger in absolute terms - measured 1.6e-3 vs the emulation, 2.6e-3 vs fp32,
+    #  emulation vs fp32 2.1e-3)
+    assert eem < 2e-3 and e32 < d_emu + 1e-3

@@ -509,3 +509,16 @@ def test_ce_loss_fwd_bwd(B, N):
     (out * 1.7).backward()
     assert abs(out.item() - ref.item()) <= 2e-6 * max(1.0, abs(ref.item()))
     assert (lg.grad.cpu() - lr.grad).abs().max().item() <= 2e-7
+
+
+def test_normalize_images_input_pipeline():
+    """Deterministic part of the reference input pipeline (train.py:1084-1090): ToTensor + Normalize(0.5, 0.5)."""
+    ops = ops_()
+    g = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (5, 32, 32, 3), generator=g, dtype=torch.uint8)
+    want = (u8.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5
+    got = ops.normalize_images(u8.to(dev()))
+    assert got.shape == (5, 3, 32, 32) and (got.cpu() - want).abs().max().item() < 1e-6
+    f = torch.rand(2, 3, 224, 224, generator=g)
+    got = ops.normalize_images(f.to(dev()), 0.5, 0.5)
+    assert (got.cpu() - (f - 0.5) / 0.5).abs().max().item() < 1e-6
