@@ -8,10 +8,14 @@
 //   O^T[d][q]  += V^T P^T    MFMA-B = P^T taken straight from the S^T accumulators (the k index
 //                            inside one 32-deep MFMA step is permuted consistently on both
 //                            operands), MFMA-A = V^T via ds_read_b64_tr_b16 (hardware transpose)
-// One workgroup = 4 waves x 32 queries; K/V tiles of 64 keys are staged global->registers->LDS
-// one tile ahead (double buffered, one barrier per tile).  LDS rows are 128 B (64 bf16) with the
-// 16-byte chunk index XOR-swizzled by (row & 7): conflict-free for both the row reads and the
-// transposed reads.
+// One workgroup = 4 waves x 32 queries; K/V tiles of 64 keys arrive by LDS-DMA (global_load_lds, inline asm) into a
+// 3-slot ring two tiles ahead, retired by a counted vmcnt, one barrier per tile.  LDS rows are 128 B (64 bf16)
+// with the 16-byte chunk index XOR-swizzled by (row & 7): conflict-free for both the row reads and the
+// transposed reads.  At head dim 64 these kernels are VALU-ISSUE bound, not MFMA bound (rocprofv3 PMC: VALU busy
+// ~70 % + MFMA issue ~18 % of the SIMD cycles): per score the exp / scale / pack work costs about as many issue
+// cycles as its share of the two MFMAs.  What the code below does about it: the bounded-score forward path (no
+// running maximum), row constants folded into initial accumulators, scales applied once to the accumulators, tile
+// addresses in scalar registers, and no compiler-visible load left pending across the tile loop (settle()).
 //
 // Backward (recompute, two kernels, no atomics, deterministic):
 //   dq kernel : same structure as forward; per KV tile S^T, dP^T = V dO^T, dS^T = P^T(dP^T - delta),
@@ -95,40 +99,10 @@ __device__ __forceinline__ void store_tile32x64(const f32x4 (&g)[4][2], char* sc
   }
 }
 
-// stage one 64-row tile (rows of 64 bf16) from `src` (row stride ld elements) : each thread 2 chunks
-struct Stage2 {
-  uint4 v[2];
-};
-__device__ __forceinline__ void stage_load(Stage2& s, const bf16* src, size_t ld, int row_base, int nrows, int tid) {
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int id = tid + 256 * t;
-    int row = row_base + (id >> 3);
-    row = row < nrows ? row : nrows - 1;
-    s.v[t] = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + (id & 7) * 8);
-  }
-}
-__device__ __forceinline__ void stage_store(const Stage2& s, char* tile, int tid) {
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int id = tid + 256 * t;
-    *reinterpret_cast<uint4*>(tile + swz_off(id >> 3, id & 7)) = s.v[t];
-  }
-}
-
 // LDS-DMA staging (global_load_lds_dwordx4 from inline asm, see gemm_common.h for why): lane L lands at
 // lds_off + 16*L.  One wave-instruction = 8 rows of a 128-byte-row tile; the XOR swizzle is realised by
 // fetching chunk (L&7) ^ (row&7).
-__device__ __forceinline__ void glds16a(const void* gsrc, unsigned lds_off) {
-  unsigned keep;
-  const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_off);
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(m)
-      : "memory");
-}
-// Same with the source address split into a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset:
+// The source address is split into a wave-uniform 64-bit base (SGPR pair) and a 32-bit per-lane byte offset:
 // the per-tile part of the address (which tile) then lives in scalar registers and costs no VALU issue slots - these
 // kernels are VALU-issue bound (PMC: VALU + MFMA issue ~ 87 % of the SIMD cycles), so address arithmetic is not free.
 __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_off) {
@@ -709,10 +683,7 @@ __device__ __forceinline__ void glds4a(const void* gsrc, unsigned lds_off) {
 // and P / dS are packed to bf16 as soon as a 16-query fragment is done, so only packed halves stay live.
 constexpr int DKV_SLOT = 2 * TILE_BYTES + 512;     // Q tile | dO tile | lse[64] | delta[64]
 constexpr int DKV_DMA = 2 * TILE_DMA + 2;          // DMA wave-instructions per wave per tile
-#ifndef NVIT_DKV_WAVES
-#define NVIT_DKV_WAVES 2
-#endif
-constexpr int DKV_WAVES = NVIT_DKV_WAVES;          // waves per SIMD the register budget is sized for
+constexpr int DKV_WAVES = 2;   // waves per SIMD the register budget is sized for (222 VGPRs; at 3 the kernel spills 118)
 
 template <bool FUSE>
 __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
