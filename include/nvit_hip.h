@@ -31,6 +31,7 @@ extern "C" {
 #define NVIT_F32 0
 #define NVIT_BF16 1
 #define NVIT_BF16X3 2 /* nvit_im2col only: bf16 "hi | lo | hi" split rows, leading dimension 3K (see there) */
+#define NVIT_BF16_F32IN 3 /* nvit_qknorm_fwd / nvit_swiglu_fwd only: fp32 inputs (unrounded GEMM outputs), bf16 outputs */
 
 int nvit_version(void);
 const char* nvit_last_error(void);

@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnvit_hip.so")
 
-F32, BF16, BF16X3 = 0, 1, 2
+F32, BF16, BF16X3, BF16_F32IN = 0, 1, 2, 3
 KID_NAMES = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "rowops", "renorm", "shadow", "patchify", "misc", "gemm_f32",
              "gemm_swiglu", "gemm_qknorm", "gemm_swiglu_bwd", "optim"]
 RENORM_ROWS_PER_ITEM = 64

@@ -279,7 +279,7 @@ struct QkArgs {
   int B, T, H, d;
 };
 
-template <int NV, typename T>
+template <int NV, typename TI, typename T>   // TI: type of the projection outputs read, T: type of the head tensors written
 __global__ __launch_bounds__(256) void qknorm_fwd_kernel(QkArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int C = a.H * a.d, M = a.B * a.T, G = a.d >> 2;  // lanes per head
@@ -290,9 +290,9 @@ __global__ __launch_bounds__(256) void qknorm_fwd_kernel(QkArgs a) {
   for (int m = blockIdx.x * ROW_WAVES + wid; m < M; m += gridDim.x * ROW_WAVES) {
     const int b = m / a.T, t = m % a.T;
     RowVec<NV> q, k, v;
-    row_load<NV, T>(q, reinterpret_cast<const T*>(a.q) + (size_t)m * a.ldq, C, lane);
-    row_load<NV, T>(k, reinterpret_cast<const T*>(a.k) + (size_t)m * a.ldk, C, lane);
-    row_load<NV, T>(v, reinterpret_cast<const T*>(a.v) + (size_t)m * a.ldv, C, lane);
+    row_load<NV, TI>(q, reinterpret_cast<const TI*>(a.q) + (size_t)m * a.ldq, C, lane);
+    row_load<NV, TI>(k, reinterpret_cast<const TI*>(a.k) + (size_t)m * a.ldk, C, lane);
+    row_load<NV, TI>(v, reinterpret_cast<const TI*>(a.v) + (size_t)m * a.ldv, C, lane);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = (i * 64 + lane) * 4;
@@ -383,8 +383,8 @@ __global__ __launch_bounds__(256) void qknorm_bwd_kernel(QkBwdArgs a) {
 
 // ------------------------------------------------------------------------------ SwiGLU
 // thread owns 4 consecutive output columns j..j+3 (inside one 16-group), loops over a row range.
-template <typename T>
-__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* uv, const float* suv, float gscale, T* x, int M,
+template <typename TI, typename T>   // TI: type of the pre-activations read, T: type of the gated output
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const TI* uv, const float* suv, float gscale, T* x, int M,
                                                           int F, int rows_per_blk) {
   const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (j >= F) return;
@@ -395,9 +395,9 @@ __global__ __launch_bounds__(256) void swiglu_fwd_kernel(const T* uv, const floa
   const int r0 = blockIdx.y * rows_per_blk;
   const int r1 = min(M, r0 + rows_per_blk);
   for (int m = r0; m < r1; ++m) {
-    const T* row = uv + (size_t)m * 2 * F + q * 32 + w;
-    const f32x4 u = load4<T>(row) * gu;
-    const f32x4 v = load4<T>(row + 16) * gv;
+    const TI* row = uv + (size_t)m * 2 * F + q * 32 + w;
+    const f32x4 u = load4<TI>(row) * gu;
+    const f32x4 v = load4<TI>(row + 16) * gv;
     f32x4 o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) o[e] = u[e] * (v[e] * sigmoidf_(v[e]));
@@ -650,12 +650,15 @@ extern "C" int nvit_qknorm_fwd(int dt, const void* q, int ldq, const void* k, in
   QkArgs a{q, k, v, ldq, ldk, ldv, sqk, c_q, qh, kh, vh, rq, rk, B, T, H, d};
   hipStream_t s = (hipStream_t)stream;
   const int grid = row_grid(B * T);
-  ProfScope ps(NVIT_KID_ROWOPS, 0.0, (double)B * T * C * (dt == NVIT_F32 ? 24.0 : 12.0), s);
+  NVIT_REQUIRE(dt == NVIT_F32 || dt == NVIT_BF16 || dt == NVIT_BF16_F32IN, "qknorm_fwd: bad dt %d", dt);
+  ProfScope ps(NVIT_KID_ROWOPS, 0.0, (double)B * T * C * (dt == NVIT_F32 ? 24.0 : dt == NVIT_BF16 ? 12.0 : 18.0), s);
   DISPATCH_NV(C, {
     if (dt == NVIT_F32)
-      hipLaunchKernelGGL((qknorm_fwd_kernel<NV, float>), dim3(grid), dim3(256), 0, s, a);
-    else
-      hipLaunchKernelGGL((qknorm_fwd_kernel<NV, bf16>), dim3(grid), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((qknorm_fwd_kernel<NV, float, float>), dim3(grid), dim3(256), 0, s, a);
+    else if (dt == NVIT_BF16)
+      hipLaunchKernelGGL((qknorm_fwd_kernel<NV, bf16, bf16>), dim3(grid), dim3(256), 0, s, a);
+    else   // fp32 projection outputs -> bf16 head tensors: normalised from the unrounded values
+      hipLaunchKernelGGL((qknorm_fwd_kernel<NV, float, bf16>), dim3(grid), dim3(256), 0, s, a);
   });
   NVIT_CHECK_LAUNCH("qknorm_fwd");
   return NVIT_OK;
@@ -695,11 +698,14 @@ extern "C" int nvit_swiglu_fwd(int dt, const void* uv, const float* suv, float g
   hipStream_t s = (hipStream_t)stream;
   const int rpb = swiglu_rows_per_blk(M, F);
   dim3 grid(cdiv(F, 1024), cdiv(M, rpb));
-  ProfScope ps(NVIT_KID_ROWOPS, 0.0, (double)M * F * 3.0 * (dt == NVIT_F32 ? 4 : 2), s);
+  NVIT_REQUIRE(dt == NVIT_F32 || dt == NVIT_BF16 || dt == NVIT_BF16_F32IN, "swiglu_fwd: bad dt %d", dt);
+  ProfScope ps(NVIT_KID_ROWOPS, 0.0, (double)M * F * (dt == NVIT_F32 ? 12.0 : dt == NVIT_BF16 ? 6.0 : 10.0), s);
   if (dt == NVIT_F32)
-    hipLaunchKernelGGL(swiglu_fwd_kernel<float>, grid, dim3(256), 0, s, (const float*)uv, suv, gscale, (float*)x, M, F, rpb);
-  else
-    hipLaunchKernelGGL(swiglu_fwd_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)uv, suv, gscale, (bf16*)x, M, F, rpb);
+    hipLaunchKernelGGL((swiglu_fwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)uv, suv, gscale, (float*)x, M, F, rpb);
+  else if (dt == NVIT_BF16)
+    hipLaunchKernelGGL((swiglu_fwd_kernel<bf16, bf16>), grid, dim3(256), 0, s, (const bf16*)uv, suv, gscale, (bf16*)x, M, F, rpb);
+  else   // fp32 pre-activations -> bf16 gated output: gated from the unrounded values (like the fused GEMM epilogue)
+    hipLaunchKernelGGL((swiglu_fwd_kernel<float, bf16>), grid, dim3(256), 0, s, (const float*)uv, suv, gscale, (bf16*)x, M, F, rpb);
   NVIT_CHECK_LAUNCH("swiglu_fwd");
   return NVIT_OK;
 }

@@ -27,7 +27,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import BF16, BF16X3, F32
+from ._lib import BF16, BF16_F32IN, BF16X3, F32
 from .config import ViTConfig
 from .kohonen import CosConsistencyFn, HuberFn, KohonenMap, MapSmoothnessFn
 
@@ -198,7 +198,8 @@ class _Runtime:
 # Functional forward / backward pieces (all compute through ops.*)
 # --------------------------------------------------------------------------------------------
 def _attn_part_fwd(rt: _Runtime, impl: int, q_src, ldq, k_src, ldk, v_src, ldv, sqk, c_q, B, T, H, d):
-    qh, kh, vh, rq, rk = ops.qknorm_fwd(rt.dt, q_src, ldq, k_src, ldk, v_src, ldv, sqk, c_q, B, T, H, d)
+    dt_in = rt.dt if rt.dt == F32 else BF16_F32IN   # the projection outputs are fp32 in both modes
+    qh, kh, vh, rq, rk = ops.qknorm_fwd(dt_in, q_src, ldq, k_src, ldk, v_src, ldv, sqk, c_q, B, T, H, d)
     o, lse = ops.attn_fwd(rt.dt, impl, qh, kh, vh, math.sqrt(d), sqk, c_q)
     return qh, kh, vh, rq, rk, o, lse
 
@@ -255,7 +256,9 @@ class _BlockFn(torch.autograd.Function):
             qh, kh, vh, rq, rk = ops.gemm_nt_qknorm(x_lo, sh[pre + "qkv.W"], M, C, 3, 0, sqk, c_q, B, T, H, d)
             o, lse = ops.attn_fwd(dt, impl, qh, kh, vh, math.sqrt(d), sqk, c_q)
         else:
-            qkv = ops.gemm_nt(x_lo, sh[pre + "qkv.W"], M, 3 * C, C, out_dtype=td, bias=sh.get(pre + "qkv.b"))
+            # small problems (128x128 GEMM kernel): the projections leave the GEMM in fp32 and are normalised from the
+            # unrounded values, like the fused epilogue of the big-problem path (one rounding, at the head tensors)
+            qkv = ops.gemm_nt(x_lo, sh[pre + "qkv.W"], M, 3 * C, C, out_dtype=torch.float32, bias=sh.get(pre + "qkv.b"))
             qh, kh, vh, rq, rk, o, lse = _attn_part_fwd(rt, impl, qkv, 3 * C, qkv[:, C:], 3 * C, qkv[:, 2 * C:],
                                                          3 * C, sqk, c_q, B, T, H, d)
             del qkv
@@ -268,8 +271,13 @@ class _BlockFn(torch.autograd.Function):
             # c_fc GEMM with suv scale + SwiGLU gate in the epilogue (writes raw uv for backward and x_mlp)
             uv, xm = ops.gemm_nt_swiglu(h1_lo, sh[pre + "fc.W"], M, 4 * C, C, sh[pre + "suv_i"], gscale)
         else:
-            uv = ops.gemm_nt(h1_lo, sh[pre + "fc.W"], M, 8 * C, C, out_dtype=td, bias=sh.get(pre + "fc.b"))
-            xm = ops.swiglu_fwd(dt, uv, suv, gscale, M, 4 * C)
+            uv32 = ops.gemm_nt(h1_lo, sh[pre + "fc.W"], M, 8 * C, C, out_dtype=torch.float32, bias=sh.get(pre + "fc.b"))
+            if dt == F32:
+                uv, xm = uv32, ops.swiglu_fwd(dt, uv32, suv, gscale, M, 4 * C)
+            else:   # gate from the unrounded pre-activations; the bf16 copy is what backward reads
+                xm = ops.swiglu_fwd(BF16_F32IN, uv32, suv, gscale, M, 4 * C)
+                uv = ops.cast(uv32, dt)
+            del uv32
         y2 = ops.gemm_nt(xm, sh[pre + "p.W"], M, C, 4 * C, out_dtype=torch.float32, bias=sh.get(pre + "p.b"))
         if with_skip:
             xn, xn_lo = ops.lerp_fwd(dt, h1, y2, mlp_alpha, c_a, skip_x=x, skip=skip_param, want_lo=(dt != F32))
@@ -390,16 +398,21 @@ class _CrossFn(torch.autograd.Function):
             qh, kh, vh, rq, rk = ops.gemm_nt_qknorm(glo_lo, sh["x.kv.W"], M, C, 2, 1, sqk, c_q, B, T, H, d, bufs)
             o, lse = ops.attn_fwd(dt, impl, qh, kh, vh, math.sqrt(d), sqk, c_q)
         else:
-            q = ops.gemm_nt(loc_lo, sh["x.q.W"], M, C, C, out_dtype=td, bias=sh.get("x.q.b"))
-            kv = ops.gemm_nt(glo_lo, sh["x.kv.W"], M, 2 * C, C, out_dtype=td, bias=sh.get("x.kv.b"))
+            q = ops.gemm_nt(loc_lo, sh["x.q.W"], M, C, C, out_dtype=torch.float32, bias=sh.get("x.q.b"))
+            kv = ops.gemm_nt(glo_lo, sh["x.kv.W"], M, 2 * C, C, out_dtype=torch.float32, bias=sh.get("x.kv.b"))
             qh, kh, vh, rq, rk, o, lse = _attn_part_fwd(rt, impl, q, C, kv, 2 * C, kv[:, C:], 2 * C, sqk, c_q, B, T,
                                                          H, d)
             del q, kv
         if not has_b and ops.fusable(dt, M, 2 * C, C):
             pr, g = ops.gemm_nt_swiglu(o, sh["x.proj.W"], M, C, C, None, 1.0)
         else:
-            pr = ops.gemm_nt(o, sh["x.proj.W"], M, 2 * C, C, out_dtype=td, bias=sh.get("x.proj.b"))
-            g = ops.swiglu_fwd(dt, pr, None, 1.0, M, C)
+            pr32 = ops.gemm_nt(o, sh["x.proj.W"], M, 2 * C, C, out_dtype=torch.float32, bias=sh.get("x.proj.b"))
+            if dt == F32:
+                pr, g = pr32, ops.swiglu_fwd(dt, pr32, None, 1.0, M, C)
+            else:
+                g = ops.swiglu_fwd(BF16_F32IN, pr32, None, 1.0, M, C)
+                pr = ops.cast(pr32, dt)
+            del pr32
         y = ops.gemm_nt(g, sh["x.out.W"], M, C, C, out_dtype=torch.float32, bias=sh.get("x.out.b"))
         x, x_lo = ops.lerp_fwd(dt, loc, y, attn_alpha, c_a, want_lo=(dt != F32))
         if dt == F32:

@@ -231,7 +231,7 @@ def norm_skip_bwd(dout: Tensor, src: Tensor, tgt: Optional[Tensor], skip: Tensor
 def qknorm_fwd(dt: int, q: Tensor, ldq: int, k: Tensor, ldk: int, v: Tensor, ldv: int, sqk: Tensor, c_q: float,
                B: int, T: int, H: int, d: int):
     dev = sqk.device
-    td = tdtype(dt)
+    td = tdtype(BF16 if dt == _lib.BF16_F32IN else dt)   # BF16_F32IN: fp32 projection outputs in, bf16 head tensors out
     qh = torch.empty((B, H, T, d), device=dev, dtype=td)
     kh = torch.empty_like(qh)
     vh = torch.empty_like(qh)
@@ -253,7 +253,8 @@ def qknorm_bwd(dt: int, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q: float, dq: Tens
 
 
 def swiglu_fwd(dt: int, uv: Tensor, suv: Optional[Tensor], gscale: float, M: int, F: int) -> Tensor:
-    x = torch.empty((M, F), device=uv.device, dtype=tdtype(dt))
+    """dt = BF16_F32IN: fp32 pre-activations in, bf16 gated output."""
+    x = torch.empty((M, F), device=uv.device, dtype=tdtype(BF16 if dt == _lib.BF16_F32IN else dt))
     check(_lib.load().nvit_swiglu_fwd(dt, _p(uv), _p(suv), gscale, _p(x), M, F, _s()), "nvit_swiglu_fwd")
     return x
 
