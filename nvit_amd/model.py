@@ -92,6 +92,10 @@ class _Runtime:
         with torch.cuda.stream(self.side):
             return fn()
 
+    def y_dtype(self) -> torch.dtype:
+        """Storage type of the branch outputs y (att_c_proj / mlp_c_proj / out_proj results, the second LERP input)."""
+        return torch.bfloat16 if (self.dt != F32 and self.model.y_bf16) else torch.float32
+
     def grad_buf(self, params, shape) -> Tensor:
         """Destination of a parameter gradient: the data-parallel wrapper's flat bucket slice when it offers one
         (`model._grad_sink`, parallel.py: gradients are produced in place, nothing is copied), else a fresh tensor.
@@ -262,7 +266,7 @@ class _BlockFn(torch.autograd.Function):
             qh, kh, vh, rq, rk, o, lse = _attn_part_fwd(rt, impl, qkv, 3 * C, qkv[:, C:], 3 * C, qkv[:, 2 * C:],
                                                          3 * C, sqk, c_q, B, T, H, d)
             del qkv
-        y = ops.gemm_nt(o, sh[pre + "o.W"], M, C, C, out_dtype=torch.float32, bias=sh.get(pre + "o.b"))
+        y = ops.gemm_nt(o, sh[pre + "o.W"], M, C, C, out_dtype=rt.y_dtype(), bias=sh.get(pre + "o.b"))
         h1, h1_lo = ops.lerp_fwd(dt, x, y, attn_alpha, c_a, want_lo=(dt != F32))
         if dt == F32:
             h1_lo = h1
@@ -278,7 +282,7 @@ class _BlockFn(torch.autograd.Function):
                 xm = ops.swiglu_fwd(BF16_F32IN, uv32, suv, gscale, M, 4 * C)
                 uv = ops.cast(uv32, dt)
             del uv32
-        y2 = ops.gemm_nt(xm, sh[pre + "p.W"], M, C, 4 * C, out_dtype=torch.float32, bias=sh.get(pre + "p.b"))
+        y2 = ops.gemm_nt(xm, sh[pre + "p.W"], M, C, 4 * C, out_dtype=rt.y_dtype(), bias=sh.get(pre + "p.b"))
         if with_skip:
             xn, xn_lo = ops.lerp_fwd(dt, h1, y2, mlp_alpha, c_a, skip_x=x, skip=skip_param, want_lo=(dt != F32))
         else:
@@ -413,7 +417,7 @@ class _CrossFn(torch.autograd.Function):
                 g = ops.swiglu_fwd(BF16_F32IN, pr32, None, 1.0, M, C)
                 pr = ops.cast(pr32, dt)
             del pr32
-        y = ops.gemm_nt(g, sh["x.out.W"], M, C, C, out_dtype=torch.float32, bias=sh.get("x.out.b"))
+        y = ops.gemm_nt(g, sh["x.out.W"], M, C, C, out_dtype=rt.y_dtype(), bias=sh.get("x.out.b"))
         x, x_lo = ops.lerp_fwd(dt, loc, y, attn_alpha, c_a, want_lo=(dt != F32))
         if dt == F32:
             x_lo = x.new_empty(0)
@@ -800,6 +804,10 @@ class ViT(nn.Module):
         # runtime (not part of the state_dict)
         self.precision = os.environ.get("NVIT_PRECISION", "bf16")
         self.attn_impl = os.environ.get("NVIT_ATTN_IMPL", "auto")
+        # bf16 mode: store the branch outputs y (the nn.Linear results that enter the LERP) in bf16, as the reference's own
+        # autocast path does (every nn.Linear returns bf16).  y only enters the stream through
+        # lam * (nrm(y) - nrm(h)) with lam ~ 0.05, so its rounding adds ~5e-6 rms to a stream error of ~2e-5.
+        self.y_bf16 = os.environ.get("NVIT_Y_BF16", "0") == "1"
         object.__setattr__(self, "_rt", _Runtime(self))
         object.__setattr__(self, "_node_sync", None)   # set by DataParallel: averages SOM nodes across ranks
         object.__setattr__(self, "_taps", None)        # tests: dict that receives the residual stream after each block
