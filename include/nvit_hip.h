@@ -306,6 +306,16 @@ int nvit_recon_bwd(int dt, const float* raw, const float* img, const float* g, v
 int nvit_ce_loss(const float* logits, const int64_t* labels, float* rowloss, float* loss, float* dlogits, int B, int N,
                  void* stream);
 
+/* ---- gradient all-reduce by direct peer reads over xGMI (nvit/train.py:438-446) --------------
+ * Symmetric flat fp32 buffers of n elements (n % 4 == 0), one per rank, mapped into this process (IPC); peer_ptrs is a
+ * HOST array of nranks (<= 8) device pointers, [rank] = this rank's own buffer.  chunk = nvit_xgmi_chunk(n, nranks).
+ * nvit_xgmi_reduce_scatter: own[rank*chunk ...] = scale * sum over ranks 0..nranks-1 (fixed order) of their chunk `rank`.
+ * nvit_xgmi_all_gather   : own[j*chunk ...] = rank j's chunk j, for every j != rank.
+ * The caller separates the phases (every rank finished writing / reduce-scatter / all-gather) with its own barrier. */
+int64_t nvit_xgmi_chunk(int64_t n, int nranks);
+int nvit_xgmi_reduce_scatter(const int64_t* peer_ptrs, int nranks, int rank, int64_t n, float scale, void* stream);
+int nvit_xgmi_all_gather(const int64_t* peer_ptrs, int nranks, int rank, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,8 +76,12 @@ SIGNATURES = {
     "nvit_som_smooth_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp],
     "nvit_recon_bwd": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "nvit_recon_loss": [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    "nvit_xgmi_chunk": [_i64, _i],
+    "nvit_xgmi_reduce_scatter": [_vp, _i, _i, _i64, _f, _vp],
+    "nvit_xgmi_all_gather": [_vp, _i, _i, _i64, _vp],
 }
-_RESTYPES = {"nvit_last_error": C.c_char_p, "nvit_prof_name": C.c_char_p, "nvit_prof_enable": None}
+_RESTYPES = {"nvit_last_error": C.c_char_p, "nvit_prof_name": C.c_char_p, "nvit_prof_enable": None,
+             "nvit_xgmi_chunk": C.c_int64}
 
 _lib = None
 

@@ -37,6 +37,13 @@ from torch import nn
 _ALIGN = 4   # elements: every slice of a flat fp32 bucket starts on a 16-byte boundary
 
 
+class _Done:
+    """Stand-in for a collective's work handle when the bucket is reduced later as part of a bigger buffer."""
+
+    def wait(self) -> None:
+        return None
+
+
 class _Bucket:
     def __init__(self, params: List[nn.Parameter]):
         self.params = params
@@ -57,11 +64,18 @@ class _Bucket:
 
 class DataParallel(nn.Module):
     def __init__(self, module: nn.Module, process_group=None, bucket_cap_mb: float = 40.0,
-                 broadcast_parameters: bool = True) -> None:
+                 broadcast_parameters: bool = True, collective: str = "rccl") -> None:
+        """collective: "rccl" (default) = bucketed torch.distributed all-reduce overlapped with backward;
+        "xgmi" = the hand-written direct reduce-scatter / all-gather over IPC-mapped buffers (nvit_amd/xgmi.py, SURVEY §8f
+        F3): all buckets live in one symmetric buffer that is reduced once at the end of backward (no overlap yet)."""
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("DataParallel needs an initialised torch.distributed process group")
+        if collective not in ("rccl", "xgmi"):
+            raise ValueError("collective must be 'rccl' or 'xgmi'")
         self.module = module
+        self.collective = collective
+        self._xg = None
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.bucket_cap = int(bucket_cap_mb * 1024 * 1024)
@@ -130,6 +144,9 @@ class DataParallel(nn.Module):
             self._launch(b)
 
     def _launch(self, b: _Bucket) -> None:
+        if self._xg is not None:   # direct xGMI collective: the whole symmetric buffer goes at the end of backward
+            b.handle = _Done()
+            return
         b.flat.div_(self.world)
         b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -185,9 +202,17 @@ class DataParallel(nn.Module):
             size += nbytes
         if cur:
             buckets.append(_Bucket(cur))
+        if self.collective == "xgmi" and buckets:
+            from .xgmi import XgmiAllReduce
+            self._xg = XgmiAllReduce(sum(b.numel for b in buckets), buckets[0].params[0].device, self.group)
+        off = 0
         for b in buckets:
             ref = b.params[0]
-            b.flat = torch.zeros(b.numel, device=ref.device, dtype=ref.dtype)
+            if self._xg is not None:   # bucket = slice of the symmetric buffer every rank maps (numel is a multiple of 4)
+                b.flat = self._xg.buffer[off: off + b.numel]
+                off += b.numel
+            else:
+                b.flat = torch.zeros(b.numel, device=ref.device, dtype=ref.dtype)
             b.index = {p: i for i, p in enumerate(b.params)}
             for p in b.params:
                 self._bucket_of[p] = b
@@ -217,6 +242,8 @@ class DataParallel(nn.Module):
                     if p.grad is None:
                         b.slice_of(i).zero_()
                 self._launch(b)
+        if self._xg is not None:
+            self._xg.all_reduce_(1.0 / self.world)
         for p in self._late:
             p.grad.div_(self.world)
             dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)

@@ -1,6 +1,6 @@
 """Worker of tests/test_gpu_dp.py: one rank of a 2-rank data-parallel run of the REAL model, both ranks on cuda:0,
 gloo backend (the 1-GPU box has no second device for RCCL).  Started as a fresh process per rank.
-usage: python tests/dp_worker.py <config> <out.json>   (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the env)"""
+usage: python tests/dp_worker.py <config> <out.json> [rccl|xgmi]   (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the env)"""
 import json
 import os
 import sys
@@ -34,6 +34,7 @@ def rel(a, b):
 
 def main():
     name, out_path = sys.argv[1], sys.argv[2]
+    collective = sys.argv[3] if len(sys.argv) > 3 else "rccl"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", init_method="env://")
@@ -47,7 +48,7 @@ def main():
         with torch.no_grad():
             for p in m.parameters():
                 p.add_(0.5)
-    dp = DataParallel(m, bucket_cap_mb=0.25)
+    dp = DataParallel(m, bucket_cap_mb=0.25, collective=collective)
     opt = m.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")
     res = {"rank": rank, "config": name}
 

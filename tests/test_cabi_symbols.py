@@ -12,7 +12,7 @@ def _declared():
     h = open(os.path.join(ROOT, "include", "nvit_hip.h")).read()
     h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
     out = {}
-    for name, args in re.findall(r"(?:int|void|const char\*)\s+(nvit_\w+)\s*\(([^;]*?)\)\s*;", h):
+    for name, args in re.findall(r"(?:int64_t|int|void|const char\*)\s+(nvit_\w+)\s*\(([^;]*?)\)\s*;", h):
         a = args.strip()
         out[name] = 0 if a in ("void", "") else len(a.split(","))
     return out

@@ -26,7 +26,7 @@ def _free_port():
     return p
 
 
-def _run(name, tmp_path):
+def _run(name, tmp_path, collective="rccl"):
     port = _free_port()
     procs, outs = [], []
     for rank in range(2):
@@ -34,7 +34,7 @@ def _run(name, tmp_path):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         out = tmp_path / f"{name}_{rank}.json"
         outs.append(out)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), name, str(out)],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), name, str(out), collective],
                                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
@@ -79,3 +79,17 @@ def test_dp_two_ranks_kohonen_head(tmp_path):
         for step in range(3):
             assert r[f"ranks_equal_step{step}"]
         assert r["params_equal_across_ranks"]
+
+
+def test_dp_two_ranks_direct_xgmi_collective(tmp_path):
+    """Same run with the hand-written reduce-scatter / all-gather instead of torch.distributed's
+    all-reduce: all buckets in one IPC-mapped symmetric buffer, reduced once at the end of backward."""
+    res = _run("mini", tmp_path, collective="xgmi")
+    for r in res:
+        for step in range(3):
+            assert r[f"ranks_equal_step{step}"] and r[f"aligned_step{step}"]
+        assert r["params_equal_across_ranks"]
+    r0 = res[0]
+    assert r0["grad_err_vs_single_process"][0] < 5e-6, r0
+    assert max(r0["grad_err_vs_single_process"]) < 3e-4 and r0["param_err_vs_single_process"] < 1e-4, r0
+    assert r0["accum_err_vs_single_process"] < 3e-4, r0
