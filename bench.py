@@ -291,6 +291,10 @@ def main() -> None:
             # algorithmic backward = 10*B*H*T^2*d (five products); the two-kernel form executes 14 (S and dP twice)
             "attn_bwd": fam_of("attn_bwd", "attn_bwd_dq_mfma + attn_bwd_dkv_mfma (10*B*H*T^2*d algorithmic)", 1.4),
         }
+        if args.precision == "bf16":
+            # fused dual patch embedding: executed flops = 3 bf16 products per element (hi*hi + lo*hi + hi*lo)
+            families["patch_embed"] = fam_of("patchify", "patch_embed (image gather -> LDS, split-operand MFMA, bias+pos epilogue; "
+                                                         "3 x 2*M*C*(Kl+Kg) executed)")
         families = {k: v for k, v in families.items() if v}
         weakest = min(families, key=lambda k: families[k]["frac"]) if families else None
         traffic, traffic_src = pmc_traffic()
@@ -320,7 +324,7 @@ def main() -> None:
         # HBM-bound kernels of the path: algorithmic bytes (as declared at each launch) / HIP-event time, vs 8 TB/s
         n_upd = opt._cache["n_elems"] if getattr(opt, "_cache", None) else sum(p.numel() for p in model.parameters())
         hbm = {}
-        for fam, label in (("rowops", "row kernels (LERP/norm_skip fwd+bwd, reductions)"), ("patchify", "im2col"),
+        for fam, label in (("rowops", "row kernels (LERP/norm_skip fwd+bwd, reductions)"),
                            ("shadow", "bf16 operand copies of the weights")):
             f = prof.get(fam)
             if f and f["ms"] > 0 and f["bytes"] > 0:

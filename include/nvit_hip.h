@@ -30,7 +30,6 @@ extern "C" {
 #define NVIT_EINVAL 1001
 #define NVIT_F32 0
 #define NVIT_BF16 1
-#define NVIT_BF16X3 2 /* nvit_im2col only: bf16 "hi | lo | hi" split rows, leading dimension 3K (see there) */
 #define NVIT_BF16_F32IN 3 /* nvit_qknorm_fwd / nvit_swiglu_fwd only: fp32 inputs (unrounded GEMM outputs), bf16 outputs */
 
 int nvit_version(void);
@@ -81,9 +80,10 @@ int nvit_renorm_weights(const int64_t* table, int n, int total_items, void* stre
  *   buffer (Q|K|V stacking); only the stated extents are written.
  *   perm: 0 identity; 1 = SwiGLU interleave of a [2F, K] matrix: shadow row 32q+w is
  *         source row 16q+w (w<16, "u") or F+16q+(w-16) (w>=16, "v");
- *         2 = split-precision image (dt = bf16 only, dstT unused): dst [rows, 3*cols] = [hi | hi | lo] with
- *         hi = bf16(src), lo = bf16(src - hi) - the weight operand of the patch-embedding GEMM whose
- *         activation rows nvit_im2col writes as [hi | lo | hi] (dt NVIT_BF16X3).
+ *         2 = split-precision image (dt = bf16 only, dstT unused): dst [rows, 2*Kp], Kp = nvit_patch_embed_kp(cols);
+ *         columns 32j..32j+31 of src become the 128-byte slice [hi32 | lo32] at dst column 64j, hi = bf16(src),
+ *         lo = bf16(src - hi) - the weight operand of nvit_patch_embed_fwd.  The padding columns of the last
+ *         slice are NOT written: allocate dst zeroed.
  *   Work items are 64x64 tiles: tiles_c = ceil(max(cols,dst_cols)/64) tile columns,
  *   ceil(max(rows,dstT_cols)/64) tile rows; first_item = prefix sum; total_items = sum.
  * Element type of dst/dstT is `dt`. */
@@ -251,10 +251,21 @@ int nvit_attn_bwd_qknorm(int dt, const void* dout, const void* qh, const void* k
 /* ---- patch embedding / head / reconstruction -------------------------------------------
  * nvit_im2col: A_l [M, ch*Pl*Pl] and A_g [M, ch*Pg*Pg] (type dt, column order (c,ph,pw)) from
  * img fp32 [B,ch,S,S]; global windows are reflect-padded by (Pg-Pl)/2 and strided by Pl
- * (model.py:286-304,407-408).  dt = NVIT_BF16X3 writes rows of 3K bf16 values [hi(x) | x - hi(x) | hi(x)]; a bf16
- * nvit_gemm_nt over K' = 3K against weights laid out [hi(w) | hi(w) | w - hi(w)] then yields the fp32-accurate
- * product (hi*hi + lo*hi + hi*lo, ~2^-16 relative) - the bf16 mode's patch embedding. */
+ * (model.py:286-304,407-408).  The exact-fp32 mode multiplies these by the patch weights with nvit_gemm_nt; the
+ * bf16 mode never materialises them (nvit_patch_embed_fwd). */
 int nvit_im2col(int dt, const float* img, void* A_l, void* A_g, int B, int ch, int S, int Pl, int Pg, void* stream);
+/* nvit_patch_embed_fwd: the dual patch embedding of the bf16 mode as ONE kernel (model.py:286-304 the two Conv2d
+ * patchifiers, :407-415 their application + position embeddings):
+ *   out_l[m] = W_l . patch_l(m) + b_l + pos_l[m % T],   out_g[m] = W_g . patch_g(m) + b_g + pos_g[m % T]   (fp32 [M, C])
+ * Patches are gathered from img fp32 [B,ch,S,S] into LDS (same geometry rules as nvit_im2col), split into bf16
+ * hi + lo on the fly and multiplied on the bf16 MFMA as hi*hi + lo*hi + hi*lo (fp32-accurate to ~2^-16 relative).
+ * w_l / w_g: split weight images [C, 2*Kp] from nvit_shadow_weights (perm 2), Kp = nvit_patch_embed_kp(ch*P*P).
+ * a_l / a_g: optional bf16 [ceil(M/256)*256, Kp] outputs = the rounded patch rows (columns >= K zero), the saved
+ * operand of the weight-gradient GEMM; NULL to skip.  b_l / b_g may be NULL. */
+int nvit_patch_embed_kp(int K);
+int nvit_patch_embed_fwd(const float* img, const void* w_l, const float* b_l, const float* pos_l, float* out_l, void* a_l,
+                         const void* w_g, const float* b_g, const float* pos_g, float* out_g, void* a_g, int B, int ch,
+                         int S, int Pl, int Pg, int C, void* stream);
 /* mean over tokens + LayerNorm(eps) (model.py:455-456, mlp_head.0): x fp32 [B,T,C] ->
  * pooled [B,C] fp32, ln [B,C] fp32 and ln_lo (type dt, ld = C), stats [B,2] = {mean, rstd}. ws [B, nchunk, C]. */
 int nvit_pool_ln_fwd(int dt, const float* x, const float* w, const float* b, float eps, float* pooled, float* ln,

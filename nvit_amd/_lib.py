@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnvit_hip.so")
 
-F32, BF16, BF16X3, BF16_F32IN = 0, 1, 2, 3
+F32, BF16, BF16_F32IN = 0, 1, 3
 KID_NAMES = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "rowops", "renorm", "shadow", "patchify", "misc", "gemm_f32",
              "gemm_swiglu", "gemm_qknorm", "gemm_swiglu_bwd", "optim"]
 RENORM_ROWS_PER_ITEM = 64
@@ -61,6 +61,8 @@ SIGNATURES = {
     "nvit_attn_bwd_qknorm": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp, _vp,
                              _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_im2col": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "nvit_patch_embed_kp": [_i],
+    "nvit_patch_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "nvit_pool_ln_fwd": [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "nvit_pool_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "nvit_som_bmu": [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp],

@@ -9,29 +9,10 @@ __device__ __forceinline__ int reflect(int i, int n) {
   return i >= n ? 2 * (n - 1) - i : i;
 }
 
-// Output element writers.  Split3 stores a bf16 "hi | lo | hi" image of each row (leading dimension 3K): against
-// weights laid out "hi | hi | lo" one ordinary bf16 GEMM over 3K then sums hi*hi + lo*hi + hi*lo, i.e. the product
-// of the un-rounded operands to ~2^-16 relative, at three bf16-MFMA passes instead of an exact-f32 MFMA GEMM.
 template <typename T>
 struct ColWriter {
   static constexpr int MUL = 1;
   static __device__ __forceinline__ void put(T* row, int K, int k, f32x4 v) { store4<T>(row + k, v); }
-};
-struct Split3 {};
-template <>
-struct ColWriter<Split3> {
-  static constexpr int MUL = 3;
-  static __device__ __forceinline__ void put(bf16* row, int K, int k, f32x4 v) {
-    f32x4 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      hi[e] = (float)(bf16)v[e];
-      lo[e] = v[e] - hi[e];
-    }
-    store4<bf16>(row + k, hi);
-    store4<bf16>(row + K + k, lo);
-    store4<bf16>(row + 2 * K + k, hi);
-  }
 };
 
 // one thread -> 4 consecutive pw of one (token, c, ph); column order (c, ph, pw)
@@ -220,13 +201,11 @@ extern "C" int nvit_im2col(int dt, const float* img, void* A_l, void* A_g, int B
   const long long n = (long long)B * G * G * ((ch * Pl * Pl + ch * Pg * Pg) / 4);
   int blocks = cdiv(n, 256);
   if (blocks > 8192) blocks = 8192;
-  NVIT_REQUIRE(dt == NVIT_F32 || dt == NVIT_BF16 || dt == NVIT_BF16X3, "im2col: bad dt %d", dt);
-  const double es = dt == NVIT_F32 ? 4.0 : (dt == NVIT_BF16X3 ? 6.0 : 2.0);
+  NVIT_REQUIRE(dt == NVIT_F32 || dt == NVIT_BF16, "im2col: bad dt %d", dt);
+  const double es = dt == NVIT_F32 ? 4.0 : 2.0;
   ProfScope ps(NVIT_KID_PATCHIFY, 0.0, (double)B * ch * S * S * 4.0 + (double)n * 4.0 * es, s);
   if (dt == NVIT_F32)
     hipLaunchKernelGGL((im2col_kernel<float, float>), dim3(blocks), dim3(256), 0, s, img, (float*)A_l, (float*)A_g, B, ch, S, Pl, Pg);
-  else if (dt == NVIT_BF16X3)
-    hipLaunchKernelGGL((im2col_kernel<Split3, bf16>), dim3(blocks), dim3(256), 0, s, img, (bf16*)A_l, (bf16*)A_g, B, ch, S, Pl, Pg);
   else
     hipLaunchKernelGGL((im2col_kernel<bf16, bf16>), dim3(blocks), dim3(256), 0, s, img, (bf16*)A_l, (bf16*)A_g, B, ch, S, Pl, Pg);
   NVIT_CHECK_LAUNCH("im2col");

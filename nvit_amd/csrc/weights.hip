@@ -159,17 +159,17 @@ __global__ __launch_bounds__(256) void shadow_kernel(const int64_t* table, int n
       const int r = r0 + ty + 4 * i, c = c0 + tx;
       float v = 0.f;
       if (perm == 2) {
-        // split-precision image of a patch-embedding weight: [hi | hi | lo] with hi = bf16(w), lo = bf16(w - hi) - the
-        // partner of the im2col rows [hi | lo | hi], so ONE bf16 GEMM over 3K sums hi*hi + lo*hi + hi*lo (model.py)
+        // split-precision image of a patch-embedding weight for patch_embed.hip: per 32 patch elements one 128-byte
+        // slice [hi32 | lo32] with hi = bf16(w), lo = bf16(w - hi); dst_ld = 2 * Kp, the zero padding of the last
+        // slice is written once by the host (the buffer is allocated zeroed)
         if constexpr (sizeof(T) == 2) {
           if (r < rows && c < cols) {
             v = src[(size_t)r * cols + c];
             const T hi = (T)v;
             const T lo = (T)(v - (float)hi);
-            T* d = dst + (size_t)r * dst_ld + c;
+            T* d = dst + (size_t)r * dst_ld + (c >> 5) * 64 + (c & 31);
             d[0] = hi;
-            d[cols] = hi;
-            d[2 * cols] = lo;
+            d[32] = lo;
           }
         }
         continue;

@@ -27,7 +27,7 @@ import torch
 from torch import nn
 
 from . import ops
-from ._lib import BF16, BF16_F32IN, BF16X3, F32
+from ._lib import BF16, BF16_F32IN, F32
 from .config import ViTConfig
 from .kohonen import CosConsistencyFn, HuberFn, KohonenMap, MapSmoothnessFn
 
@@ -141,9 +141,11 @@ class _Runtime:
         if dt == F32:
             ent.append((w2(m.local_patch_embed.weight), new("pe_l", C, Kl), Kl, Kl, None, 0, 0, 0))
             ent.append((w2(m.global_patch_embed[1].weight), new("pe_g", C, Kg), Kg, Kg, None, 0, 0, 0))
-        else:   # split-precision [hi | hi | lo] images, K' = 3K (see _EmbedFn)
-            ent.append((w2(m.local_patch_embed.weight), new("pe_l", C, 3 * Kl), 3 * Kl, Kl, None, 0, 0, 2))
-            ent.append((w2(m.global_patch_embed[1].weight), new("pe_g", C, 3 * Kg), 3 * Kg, Kg, None, 0, 0, 2))
+        else:   # split-precision images, one [hi32 | lo32] slice per 32 patch elements (see _EmbedFn); padding stays zero
+            for name, w, K in (("pe_l", m.local_patch_embed.weight, Kl), ("pe_g", m.global_patch_embed[1].weight, Kg)):
+                Kp = ops.patch_kp(K)
+                sh[name] = torch.zeros((C, 2 * Kp), device=device, dtype=td)
+                ent.append((w2(w), sh[name], 2 * Kp, K, None, 0, 0, 2))
 
         def stack(prefix, lins, perm=0):
             """shadow of row-stacked Linear weights [sum rows, K] and its transpose [K, sum rows]."""
@@ -493,22 +495,22 @@ class _EmbedFn(torch.autograd.Function):
         T = rt.model.n_tokens
         M = B * T
         Kl, Kg = cfg.channels * Pl * Pl, cfg.channels * Pg * Pg
-        # Precision policy of the bf16 mode: the two patch-embedding GEMMs are computed to fp32 accuracy.  They are
-        # 0.55 % of the step's FLOPs but their output IS the residual stream, so a bf16-operand rounding here (1.6e-3
-        # relative) reaches the logits undamped, while every later update is scaled by the LERP rate (~0.05): max
-        # |dlogit| vs the fp32 oracle drops 1.2e-3 -> 1.5e-4 (micro), 1.4e-3 -> 5.1e-4 (mini), 2.6e-3 -> 9.4e-4 (tiny).
-        # Done on the bf16 MFMA path by operand splitting: x = hi + lo, w = hi + lo (bf16 each); im2col writes rows
-        # [hi|lo|hi], the weight image is [hi|hi|lo], and one bf16 GEMM over K' = 3K sums hi*hi + lo*hi + hi*lo
-        # (missing lo*lo ~ 2^-16 relative) - three bf16 passes instead of an 8x slower exact-f32 MFMA GEMM.
+        # Precision policy of the bf16 mode: the two patch embeddings are computed to fp32 accuracy.  They are 0.55 % of
+        # the step's FLOPs but their output IS the residual stream, so a bf16-operand rounding here (1.6e-3 relative)
+        # reaches the logits undamped, while every later update is scaled by the LERP rate (~0.05): max |dlogit| vs
+        # the fp32 oracle drops 1.2e-3 -> 1.5e-4 (micro), 1.4e-3 -> 5.1e-4 (mini), 2.6e-3 -> 9.4e-4 (tiny).
+        # Done on the bf16 MFMA path by operand splitting, x = hi + lo, w = hi + lo (bf16 each), three products
+        # hi*hi + lo*hi + hi*lo (missing lo*lo ~ 2^-16 relative) - in ONE kernel that gathers the patches from the
+        # image into LDS (no im2col matrix in HBM), adds bias + position embedding in its epilogue, and leaves the
+        # bf16 patch rows behind for the weight gradient (patch_embed.hip).
         if rt.dt == F32:
             A_l, A_g = ops.im2col(F32, img, Pl, Pg)
             loc = ops.gemm_nt(A_l, rt.sh["pe_l"], M, C, Kl, bias=bl, rowadd=posl.reshape(T, C), rowadd_period=T)
             glo = ops.gemm_nt(A_g, rt.sh["pe_g"], M, C, Kg, bias=bg, rowadd=posg.reshape(T, C), rowadd_period=T)
         else:
-            A_l, A_g = ops.im2col(BF16X3, img, Pl, Pg)
-            # (the [hi | hi | lo] weight images are part of the shadow set, built by nvit_shadow_weights)
-            loc = ops.gemm_nt(A_l, rt.sh["pe_l"], M, C, 3 * Kl, bias=bl, rowadd=posl.reshape(T, C), rowadd_period=T)
-            glo = ops.gemm_nt(A_g, rt.sh["pe_g"], M, C, 3 * Kg, bias=bg, rowadd=posg.reshape(T, C), rowadd_period=T)
+            # (the split weight images are part of the shadow set, built by nvit_shadow_weights)
+            loc, glo, A_l, A_g = ops.patch_embed_fwd(img, rt.sh["pe_l"], bl, posl.reshape(T, C), rt.sh["pe_g"], bg,
+                                                     posg.reshape(T, C), Pl, Pg, C)
         ctx.rt = rt
         ctx.dims = (B, T, C, M, Kl, Kg)
         ctx.par = (wl, wg)
@@ -518,7 +520,7 @@ class _EmbedFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloc, dglo):
-        A_l, A_g = ctx.saved_tensors   # bf16 mode: the leading K columns of the split image are the bf16 operand
+        A_l, A_g = ctx.saved_tensors   # bf16 mode: [Mpad, Kp] patch rows written by the fused forward kernel
         rt = ctx.rt
         B, T, C, M, Kl, Kg = ctx.dims
         dev = A_l.device
@@ -526,7 +528,7 @@ class _EmbedFn(torch.autograd.Function):
         for dy, A, K, pw in ((dloc, A_l, Kl, ctx.par[0]), (dglo, A_g, Kg, ctx.par[1])):
             dy = dy.contiguous()
             dy_lo = dy if rt.dt == F32 else ops.cast(dy, rt.dt)
-            gw = ops.gemm_tn(dy_lo, A[:, :K], rt.grad_buf((pw,), (C, K)), M, C, K)
+            gw = ops.gemm_tn(dy_lo, A[:M, :K], rt.grad_buf((pw,), (C, K)), M, C, K)
             dpos = torch.empty((T, C), device=dev, dtype=torch.float32)
             ops.colsum(dy, M, C, dpos, False, period=T)
             db = torch.empty((C,), device=dev, dtype=torch.float32)

@@ -377,15 +377,43 @@ def attn_bwd_qknorm(dout: Tensor, qh: Tensor, kh: Tensor, vh: Tensor, o: Tensor,
 
 # ----------------------------------------------------------------------------- embed / head
 def im2col(dt: int, img: Tensor, Pl: int, Pg: int):
-    """dt = _lib.BF16X3: rows are bf16 [hi | lo | hi] images of width 3K (see nvit_im2col)."""
     B, ch, S, _ = img.shape
     T = (S // Pl) ** 2
-    mul = 3 if dt == _lib.BF16X3 else 1
-    td = torch.bfloat16 if dt == _lib.BF16X3 else tdtype(dt)
-    A_l = torch.empty((B * T, mul * ch * Pl * Pl), device=img.device, dtype=td)
-    A_g = torch.empty((B * T, mul * ch * Pg * Pg), device=img.device, dtype=td)
+    td = tdtype(dt)
+    A_l = torch.empty((B * T, ch * Pl * Pl), device=img.device, dtype=td)
+    A_g = torch.empty((B * T, ch * Pg * Pg), device=img.device, dtype=td)
     check(_lib.load().nvit_im2col(dt, _p(img), _p(A_l), _p(A_g), B, ch, S, Pl, Pg, _s()), "nvit_im2col")
     return A_l, A_g
+
+
+def patch_kp(K: int) -> int:
+    """patch length padded to whole 32-element stages of nvit_patch_embed_fwd"""
+    return round_up(K, 32)
+
+
+def patch_embed_fwd(img: Tensor, w_l: Tensor, b_l: Optional[Tensor], pos_l: Tensor, w_g: Tensor, b_g: Optional[Tensor],
+                    pos_g: Tensor, Pl: int, Pg: int, Cc: int, save_rows: bool = True):
+    """Fused dual patch embedding of the bf16 mode -> loc, glo fp32 [M, C] and (save_rows) the bf16 patch rows
+    a_l [Mpad, Kp_l], a_g [Mpad, Kp_g] for the weight gradients.  w_l / w_g: split images [C, 2*Kp] (shadow perm 2)."""
+    B, ch, S, _ = img.shape
+    T = (S // Pl) ** 2
+    M = B * T
+    Kpl, Kpg = patch_kp(ch * Pl * Pl), patch_kp(ch * Pg * Pg)
+    assert w_l.shape == (Cc, 2 * Kpl) and w_g.shape == (Cc, 2 * Kpg) and w_l.dtype == torch.bfloat16
+    assert pos_l.shape == (T, Cc) and pos_g.shape == (T, Cc) and img.dtype == torch.float32 and img.is_contiguous()
+    _chk_dev(img, w_l, w_g, pos_l, pos_g)
+    dev = img.device
+    loc = torch.empty((M, Cc), device=dev, dtype=torch.float32)
+    glo = torch.empty((M, Cc), device=dev, dtype=torch.float32)
+    a_l = a_g = None
+    if save_rows:
+        Mpad = round_up(M, 256)
+        a_l = torch.empty((Mpad, Kpl), device=dev, dtype=torch.bfloat16)
+        a_g = torch.empty((Mpad, Kpg), device=dev, dtype=torch.bfloat16)
+    check(_lib.load().nvit_patch_embed_fwd(_p(img), _p(w_l), _p(b_l), _p(pos_l), _p(loc), _p(a_l), _p(w_g), _p(b_g),
+                                           _p(pos_g), _p(glo), _p(a_g), B, ch, S, Pl, Pg, Cc, _s()),
+          "nvit_patch_embed_fwd")
+    return loc, glo, a_l, a_g
 
 
 def pool_ln_fwd(dt: int, x: Tensor, w: Tensor, b: Tensor, eps: float, B: int, T: int, Cc: int):

@@ -490,8 +490,11 @@ def _full_size_bf16_parity(name, batch, grads: bool):
         # the bar: within 1e-3 (or 5e-4 of the logit range, whichever is larger: Large has |logit|max 2.7) of the oracle
         # that rounds the same GEMM operands to bf16 ...
         assert eem < max(1e-3, 5e-4 * lmax), (tag, eem)
-        # ... and no further from the fp32 oracle than that emulation is, plus 5e-4
-        assert e32 < d_emu + 5e-4, (tag, e32, d_emu)
+        # ... and no further from the fp32 oracle than that emulation is: the whole logit field in rms (+5 %), and its
+        # maximum (one of ~2 000 values of two superposed error fields; it moves by up to 13 % with nothing but the
+        # summation order of the kernels, measured over the round's kernel variants) within 15 % + 2e-4
+        assert rms(lb - l32) < 1.05 * rms(lem - l32) + 1e-5, (tag, rms(lb - l32), rms(lem - l32))
+        assert e32 < 1.15 * d_emu + 2e-4, (tag, e32, d_emu)
         # no kernel term that grows with depth beyond what operand rounding explains: per layer, the HIP stream is
         # at most as far from the emulation as the emulation is from fp32 (x2 slack), elementwise max over [B,T,C]
         for i, (a, b) in enumerate(zip(leem, lo)):

@@ -105,20 +105,79 @@ def test_renorm_and_shadow():
         assert torch.equal(dstT.float().cpu()[:, 100:], torch.full((40, 28), 9.0))
 
 
+def _split_image(w):
+    """host restatement of the perm=2 shadow layout: per 32 columns one [hi32 | lo32] slice, zero padded"""
+    rows, K = w.shape
+    Kp = (K + 31) // 32 * 32
+    hi = w.bfloat16()
+    lo = (w - hi.float()).bfloat16()
+    img = torch.zeros(rows, 2 * Kp, dtype=torch.bfloat16)
+    for j in range(Kp // 32):
+        n = min(32, K - 32 * j)
+        img[:, 64 * j: 64 * j + n] = hi[:, 32 * j: 32 * j + n]
+        img[:, 64 * j + 32: 64 * j + 32 + n] = lo[:, 32 * j: 32 * j + n]
+    return img, hi, lo
+
+
 def test_shadow_split_precision_image():
-    """perm=2: [hi | hi | lo] bf16 image of a patch-embedding weight; hi + lo reproduces the fp32 value to 2^-16."""
+    """perm=2: per 32 patch elements a [hi32 | lo32] bf16 slice of a patch-embedding weight; hi + lo reproduces the
+    fp32 value to 2^-16; the padding of the last slice is left as allocated (zero)."""
     ops = ops_()
     from nvit_amd._lib import BF16
     w = rnd(100, 72, seed=9, scale=0.1)
-    dst = torch.full((100, 3 * 72), 9.0, device=dev(), dtype=torch.bfloat16)
-    t, n = ops.shadow_table([(w.to(dev()), dst, 3 * 72, 72, None, 0, 0, 2)], dev())
+    Kp = ops.patch_kp(72)
+    assert Kp == 96
+    dst = torch.zeros((100, 2 * Kp), device=dev(), dtype=torch.bfloat16)
+    t, n = ops.shadow_table([(w.to(dev()), dst, 2 * Kp, 72, None, 0, 0, 2)], dev())
     ops.shadow_weights(t, n, BF16)
-    got = dst.float().cpu()
-    hi = w.bfloat16()
-    lo = (w - hi.float()).bfloat16()
-    assert torch.equal(got[:, :72], hi.float()) and torch.equal(got[:, 72:144], hi.float())
-    assert torch.equal(got[:, 144:], lo.float())
-    assert (got[:, :72] + got[:, 144:] - w).abs().max().item() < 2.0 ** -16 * w.abs().max().item()
+    want, hi, lo = _split_image(w)
+    assert torch.equal(dst.cpu().float(), want.float())
+    assert (hi.float() + lo.float() - w).abs().max().item() < 2.0 ** -16 * w.abs().max().item()
+
+
+@pytest.mark.parametrize("B,ch,S,Pl,Pg,C", [
+    (2, 3, 224, 8, 16, 768),     # Base geometry (T=784, K=192/768), M = 1568 -> a partial 256-token tile
+    (3, 3, 224, 16, 32, 1024),   # 16/32 patches, C=1024
+    (5, 3, 32, 4, 8, 192),       # pad = 2: runs straddle the border (scalar gather), K=48 -> zero-padded stage, C < 256
+    (2, 3, 64, 8, 32, 320),      # pad = 12 > patch: deep reflection, C not a multiple of 256
+    (2, 1, 48, 8, 8, 64),        # one channel, global window = local window
+])
+def test_fused_patch_embed(B, ch, S, Pl, Pg, C):
+    """nvit_patch_embed_fwd (gather -> LDS -> split-operand MFMA, bias + pos epilogue) against fp64 im2col GEMMs of
+    the un-rounded operands (reference model.py:286-304,407-415), and its saved bf16 patch rows bit for bit."""
+    ops = ops_()
+    from nvit_amd._lib import BF16
+    d = dev()
+    T = (S // Pl) ** 2
+    M = B * T
+    Kl, Kg = ch * Pl * Pl, ch * Pg * Pg
+    img = rnd(B, ch, S, S, seed=1)
+    wl, wg = rnd(C, Kl, seed=2, scale=Kl ** -0.5), rnd(C, Kg, seed=3, scale=Kg ** -0.5)
+    bl, bg = rnd(C, seed=4, scale=0.1), rnd(C, seed=5, scale=0.1)
+    pl, pg = rnd(T, C, seed=6, scale=0.02), rnd(T, C, seed=7, scale=0.02)
+    sh = []
+    ent = []
+    for w, K in ((wl, Kl), (wg, Kg)):
+        Kp = ops.patch_kp(K)
+        sh.append(torch.zeros((C, 2 * Kp), device=d, dtype=torch.bfloat16))
+        ent.append((w.to(d), sh[-1], 2 * Kp, K, None, 0, 0, 2))
+    t, n = ops.shadow_table(ent, d)
+    ops.shadow_weights(t, n, BF16)
+    loc, glo, a_l, a_g = ops.patch_embed_fwd(img.to(d), sh[0], bl.to(d), pl.to(d), sh[1], bg.to(d), pg.to(d), Pl, Pg, C)
+    Al = O.im2col(img, Pl, Pl, 0).reshape(M, Kl)
+    Ag = O.im2col(img, Pg, Pl, (Pg - Pl) // 2).reshape(M, Kg)
+    for out, A, w, b, pos, a_hi, K in ((loc, Al, wl, bl, pl, a_l, Kl), (glo, Ag, wg, bg, pg, a_g, Kg)):
+        ref = (A.double() @ w.double().t() + b.double()).reshape(B, T, C) + pos.double()
+        err = (out.cpu().double().reshape(B, T, C) - ref).abs().max().item()
+        # missing lo*lo term: 2^-16 per product, random signs over K terms; fp32 accumulation
+        assert err < 1e-5 * max(1.0, ref.abs().max().item()), (err, K)
+        rows = a_hi.cpu()[:M]
+        assert torch.equal(rows[:, :K].float(), A.bfloat16().float())
+        assert torch.equal(rows[:, K:].float(), torch.zeros(M, rows.shape[1] - K))
+    # without bias and without the saved rows
+    loc2, glo2, a2, _ = ops.patch_embed_fwd(img.to(d), sh[0], None, pl.to(d), sh[1], None, pg.to(d), Pl, Pg, C, save_rows=False)
+    assert a2 is None
+    assert (loc2.cpu() + bl - loc.cpu()).abs().max().item() < 1e-6 and (glo2.cpu() + bg - glo.cpu()).abs().max().item() < 1e-6
 
 
 @pytest.mark.parametrize("C", [64, 192, 768, 1024])

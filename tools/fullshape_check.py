@@ -84,8 +84,6 @@ def check_all(B: int = 128, T: int = 784, C: int = 768, H: int = 12, verbose: bo
         (C, 2 * C, torch.float32, False, ""),        # cross k/v data gradient
         (C, C, bf, False, ""),                       # att_c_proj data gradient (bf16 out)
         (C, 2 * C, bf, False, ""),                   # cross proj data gradient (bf16 out)
-        (C, 576, torch.float32, False, "bias+pos"),  # local patch embedding (split operands, K' = 3*192)
-        (C, 2304, torch.float32, False, "bias+pos"),  # global patch embedding (K' = 3*768)
         (192, C, torch.float32, False, "bias"),      # reconstruction head (256x128 tiles)
     ]
     for N, K, odt, acc, extra in nt_cases:
@@ -110,6 +108,38 @@ def check_all(B: int = 128, T: int = 784, C: int = 768, H: int = 12, verbose: bo
         rep.add(f"gemm_nt M={M} N={N} K={K} out={'f32' if odt == torch.float32 else 'bf16'}"
                 f"{' +=' if acc else ''} {extra}", err, tol)
         del A, W, out, ref, base
+
+    # ---------------------------------------------------------------- fused dual patch embedding (gather + split-operand MFMA)
+    # reference: fp32 unfold of the (reflect-padded) image on the GPU, fp64 product of the un-rounded operands, rows
+    # sampled from every 256-token tile.  Only for the square geometry T = G*G tokens of 8x8 / 16x16 patches.
+    G = math.isqrt(T)
+    if G * G == T:
+        import torch.nn.functional as Fn
+        ch, Pl, Pg = 3, 8, 16
+        S = G * Pl
+        pad = (Pg - Pl) // 2
+        img = _rnd((B, ch, S, S), 16, dev, dtype=torch.float32)
+        sh, ws = [], []
+        for K, seed in ((ch * Pl * Pl, 17), (ch * Pg * Pg, 18)):
+            w = _rnd((C, K), seed, dev, scale=1.0 / math.sqrt(K), dtype=torch.float32)
+            Kp = ops.patch_kp(K)
+            img_w = torch.zeros((C, 2 * Kp), device=dev, dtype=bf)
+            t_, n_ = ops.shadow_table([(w, img_w, 2 * Kp, K, None, 0, 0, 2)], dev)
+            ops.shadow_weights(t_, n_, BF16)
+            sh.append(img_w)
+            ws.append(w)
+        b_l, b_g = (_rnd((C,), s_, dev, scale=0.1, dtype=torch.float32) for s_ in (19, 20))
+        p_l, p_g = (_rnd((T, C), s_, dev, scale=0.02, dtype=torch.float32) for s_ in (24, 25))
+        loc, glo, a_l, a_g = ops.patch_embed_fwd(img, sh[0], b_l, p_l, sh[1], b_g, p_g, Pl, Pg, C)
+        A_l = Fn.unfold(img, Pl, stride=Pl).transpose(1, 2).reshape(M, -1)[rows]
+        A_g = Fn.unfold(Fn.pad(img, (pad,) * 4, mode="reflect"), Pg, stride=Pl).transpose(1, 2).reshape(M, -1)[rows]
+        for name, out, A, w, b, pos, a_hi in (("local", loc, A_l, ws[0], b_l, p_l, a_l), ("global", glo, A_g, ws[1], b_g, p_g, a_g)):
+            ref = A.double() @ w.double().t() + b.double() + pos[rows % T].double()
+            err = (out[rows].double() - ref).abs().max().item()
+            rep.add(f"patch_embed {name} M={M} K={A.shape[1]} (fused gather, hi/lo split)", err, 1e-5 * max(1.0, ref.abs().max().item()))
+            e_rows = (a_hi[rows][:, :A.shape[1]].float() - A.to(bf).float()).abs().max().item()
+            rep.add(f"patch_embed {name} saved bf16 patch rows (exact)", e_rows, 1e-30)
+        del img, loc, glo, a_l, a_g, A_l, A_g, sh, ws
 
     # ---------------------------------------------------------------- EPI 3: SwiGLU forward (c_fc, cross proj)
     for F, use_gs in ((4 * C, True), (C, False)):
