@@ -147,13 +147,21 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
       bp[i] = g.B + ((size_t)rb * g.ldb + (size_t)gc * EPC) * sizeof(T);
     }
   };
+#ifdef NVIT_PROBE_NO_DMA
+  int probe_issued = 0;   // tools/probes/gemm_parts.hip: only the first NSLOT stages are really fetched
+#endif
   auto issue_stage = [&]() {
     const unsigned bo = lds_base + wave_off + (unsigned)l_slot * SLOT_BYTES;
     const size_t ko = (size_t)l_k * ROWB;
+#ifdef NVIT_PROBE_NO_DMA
+    if (probe_issued++ < NSLOT)
+#endif
+    {
 #pragma unroll
-    for (int i = 0; i < Cfg::A_DMA; ++i) glds16(ap[i] + ko, bo + i * 8192);
+      for (int i = 0; i < Cfg::A_DMA; ++i) glds16(ap[i] + ko, bo + i * 8192);
 #pragma unroll
-    for (int i = 0; i < Cfg::B_DMA; ++i) glds16(bp[i] + ko, bo + A_BYTES + i * 8192);
+      for (int i = 0; i < Cfg::B_DMA; ++i) glds16(bp[i] + ko, bo + A_BYTES + i * 8192);
+    }
     l_slot = l_slot == NSLOT - 1 ? 0 : l_slot + 1;
     if (++l_k == nt) {
       l_k = 0;
@@ -221,6 +229,7 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
     // a stage is issued at the top of this iteration iff the load cursor still has work
     const bool issued_now = DYN ? l_valid : (s + NSLOT - 1 < total_stages);
     if (issued_now) issue_stage();
+#ifndef NVIT_PROBE_NO_MFMA
     {
       // Software-pipelined fragment stream.  The stage is 2*FM "steps" of 4 MFMAs (one A fragment against the
       // four B fragments of its k-half).  All ds_read_b128 are written first, in the order the steps consume
@@ -275,11 +284,15 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
 #undef RA
 #undef RB
     }
+#endif
     bool stored = false, full_tile = false, more = true;
     if (++c_k == nt) {
       int m0, n0;
       tile_of(c_tile, m0, n0);
       full_tile = NST > 0 && m0 + PBM <= g.M && n0 + PBN <= g.N;
+#ifdef NVIT_PROBE_NO_EPI
+      if (g.rowadd_period == -77)   // never true: keeps the accumulators alive without executing the stores
+#endif
       {
         char* scratch = smem + NSLOT * SLOT_BYTES + wid * 2048;
         if constexpr (EPI == 1)

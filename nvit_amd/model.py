@@ -484,7 +484,8 @@ class _CrossFn(torch.autograd.Function):
 
 
 class _EmbedFn(torch.autograd.Function):
-    """Dual patch embedding + position embeddings (reference model.py:407-415) as im2col GEMMs."""
+    """Dual patch embedding + position embeddings (reference model.py:286-304,407-415): one fused gather + MFMA kernel in
+    the bf16 mode, im2col + exact-f32 GEMMs in the fp32 mode."""
 
     @staticmethod
     def forward(ctx, img, rt, wl, bl, posl, wg, bg, posg):
