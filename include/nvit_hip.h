@@ -284,7 +284,8 @@ int nvit_recon_loss(const float* raw, const float* img, float* part, int nblk, f
  * nvit_gather_rows / nvit_scatter_rows: repr = nodes[idx] (kohonen.py:117) and its backward (fixed order).
  * nvit_som_update: KohonenMap.update_nodes (kohonen.py:121-165) for the whole batch, in place on nodes [gm*gn, C]:
  *   B sequential steps; step i uses the BMU of FLAT token i and sample i mean-pooled T*C -> C,
- *   strength lr_alpha * exp(-d2 / (2 sigma^2)), d2 = periodic grid distance. v_ws [B,C], s_ws [B,gm*gn].
+ *   strength lr_alpha * exp(-d2 / (2 sigma^2)), d2 = squared grid distance, wrapped around the map edges when
+ *   periodic != 0 (kohonen.py:80-98). v_ws [B,C], s_ws [B,gm*gn].
  * nvit_cos_consistency_*: 1 - mean_m cos(a_m, b_m) (model.py:482-491); stats [M,3] saved for backward.
  * nvit_huber_*: F.huber_loss(a, b) with delta 1, mean (model.py:441-442).
  * nvit_som_smooth_*: mean over tokens and 8 periodic grid neighbours of ||node[idx] - node[nb]|| for ONE map
@@ -297,7 +298,7 @@ int nvit_scatter_rows(const float* dout, const int64_t* idx, float* dnodes, int6
 /* out[M,N] fp32 one-hot rows of idx: the balanced form of the scatter is nvit_gemm_tn(onehot, dout) (exact). */
 int nvit_onehot(const int64_t* idx, float* out, int64_t M, int N, void* stream);
 int nvit_som_update(float* nodes, const float* x, const int64_t* idx, float lr_alpha, float sigma, int gm, int gn,
-                    float* v_ws, float* s_ws, int B, int T, int C, void* stream);
+                    int periodic, float* v_ws, float* s_ws, int B, int T, int C, void* stream);
 int nvit_cos_consistency_fwd(const float* a, const float* b, float* stats, float* part, int nblk, float* loss,
                              int64_t M, int C, void* stream);
 int nvit_cos_consistency_bwd(const float* a, const float* b, const float* stats, const float* g, float* da, float* db,

@@ -110,7 +110,7 @@ __global__ void onehot_kernel(const long long* idx, float* out, long long M, int
 // pooled sample vectors v[i][c] = mean(flat_i[c*T .. c*T+T-1]), flat_i = x[i] viewed as T*C floats; and the
 // update strengths s[i][node] = la * exp(-d2(node, bmu_i) / (2 sigma^2)), d2 = periodic grid distance^2
 __global__ void som_prepare_kernel(const float* x, const long long* idx, float* v, float* strength, int B, int T, int C,
-                                   int Nn, int gm, int gn, float la, float inv2s2) {
+                                   int Nn, int gm, int gn, float la, float inv2s2, int periodic) {
   const int i = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const float* p = x + ((size_t)i * T * C) + (size_t)c * T;
@@ -125,10 +125,11 @@ __global__ void som_prepare_kernel(const float* x, const long long* idx, float* 
     float best = INFINITY;
     const int oi[9] = {0, -gm, gm, -gm, gm, 0, 0, -gm, gm};
     const int oj[9] = {0, -gn, gn, 0, 0, -gn, gn, gn, -gn};
+    const int nk = periodic ? 9 : 1;   // non-periodic map: the un-shifted grid only (kohonen.py:95-96)
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
       const float di = (float)(ni + oi[k] - bi), dj = (float)(nj + oj[k] - bj);
-      best = fminf(best, di * di + dj * dj);
+      if (k < nk) best = fminf(best, di * di + dj * dj);
     }
     strength[(size_t)i * Nn + n] = la * expf(-best * inv2s2);
   }
@@ -377,13 +378,13 @@ extern "C" int nvit_onehot(const int64_t* idx, float* out, int64_t M, int N, voi
 }
 
 extern "C" int nvit_som_update(float* nodes, const float* x, const int64_t* idx, float lr_alpha, float sigma, int gm,
-                               int gn, float* v_ws, float* s_ws, int B, int T, int C, void* stream) {
+                               int gn, int periodic, float* v_ws, float* s_ws, int B, int T, int C, void* stream) {
   const int Nn = gm * gn;
   NVIT_REQUIRE(B > 0 && T > 0 && C > 0 && Nn > 0 && (int64_t)B <= (int64_t)B * T, "som_update: bad shape");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(NVIT_KID_MISC, 0.0, (double)B * T * C * 4.0, s);
   hipLaunchKernelGGL(som_prepare_kernel, dim3(B), dim3(256), 0, s, x, (const long long*)idx, v_ws, s_ws, B, T, C, Nn, gm,
-                     gn, lr_alpha, 1.0f / (2.0f * sigma * sigma));
+                     gn, lr_alpha, 1.0f / (2.0f * sigma * sigma), periodic);
   NVIT_CHECK_LAUNCH("som_prepare");
   hipLaunchKernelGGL(som_update_kernel, dim3(Nn), dim3(256), 0, s, nodes, v_ws, s_ws, B, C, Nn);
   NVIT_CHECK_LAUNCH("som_update");

@@ -83,8 +83,6 @@ class KohonenMap(nn.Module):
     def __init__(self, input_dim: int, num_nodes: int, alpha: float = 0.01, sigma: Optional[float] = None,
                  periodic: bool = True) -> None:
         super().__init__()
-        if not periodic:
-            raise NotImplementedError("only the periodic topology (the reference default, the only one it uses)")
         self.m = int(num_nodes ** 0.5)
         self.n = num_nodes // self.m
         self.grid_size = self.m * self.n
@@ -95,16 +93,19 @@ class KohonenMap(nn.Module):
         locs = torch.tensor([[i, j] for i in range(self.m) for j in range(self.n)], dtype=torch.long)
         self.register_buffer("locations", locs)
         self.sigma = (self.m * self.n) ** 0.5 / 2.0 if sigma is None else float(sigma)
-        offsets = [[-self.m, -self.n], [self.m, self.n], [-self.m, 0], [self.m, 0], [0, -self.n], [0, self.n],
-                   [-self.m, self.n], [self.m, -self.n]]
-        self.register_buffer("offsets", torch.tensor(offsets))
+        if periodic:   # (the reference registers the wrap offsets only for the periodic map, kohonen.py:70-78)
+            offsets = [[-self.m, -self.n], [self.m, self.n], [-self.m, 0], [self.m, 0], [0, -self.n], [0, self.n],
+                       [-self.m, self.n], [self.m, -self.n]]
+            self.register_buffer("offsets", torch.tensor(offsets))
 
     def get_neighborhood_distances(self, bmu_loc: Tensor) -> Tensor:
-        """Squared grid distance of every node to `bmu_loc` ([2]: row, col) on the periodic map: the minimum over the
+        """Squared grid distance of every node to `bmu_loc` ([2]: row, col); on the periodic map the minimum over the
         un-shifted grid and its 8 wrapped copies (reference kohonen.py:80-98).  Index arithmetic on [m*n, 2] integers
         (the SOM update kernel recomputes the same quantity per node in registers, kohonen.hip); returns fp32 [m*n]."""
         loc = self.locations.float()
         bmu = bmu_loc.to(loc.device).float().reshape(1, 2)
+        if not self.periodic:
+            return ((loc - bmu) ** 2).sum(-1)
         shifts = torch.cat((torch.zeros(1, 2, device=loc.device), self.offsets.float()), dim=0)   # [9, 2]
         d = loc.unsqueeze(0) + shifts.unsqueeze(1) - bmu.unsqueeze(0)                              # [9, m*n, 2]
         return (d * d).sum(-1).min(dim=0).values
@@ -129,4 +130,4 @@ class KohonenMap(nn.Module):
             raise ValueError("update_nodes expects x of shape [B, T, C]")
         B, T, _ = x.shape
         ops.som_update(self.nodes.data, x.detach().contiguous().float(), winning_indices.reshape(-1).contiguous(),
-                       float(learning_rate) * float(self.alpha), self.sigma, self.m, self.n, B, T)
+                       float(learning_rate) * float(self.alpha), self.sigma, self.m, self.n, B, T, periodic=self.periodic)

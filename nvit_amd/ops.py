@@ -481,12 +481,12 @@ def scatter_rows(dout: Tensor, idx: Tensor, N: int) -> Tensor:
 
 
 def som_update(nodes: Tensor, x: Tensor, idx: Tensor, lr_alpha: float, sigma: float, gm: int, gn: int, B: int,
-               T: int) -> None:
+               T: int, periodic: bool = True) -> None:
     Cc = nodes.shape[1]
     v_ws = torch.empty((B, Cc), device=nodes.device, dtype=torch.float32)
     s_ws = torch.empty((B, gm * gn), device=nodes.device, dtype=torch.float32)
-    check(_lib.load().nvit_som_update(_p(nodes), _p(x), _p(idx), lr_alpha, sigma, gm, gn, _p(v_ws), _p(s_ws), B, T, Cc,
-                                      _s()), "nvit_som_update")
+    check(_lib.load().nvit_som_update(_p(nodes), _p(x), _p(idx), lr_alpha, sigma, gm, gn, int(periodic), _p(v_ws), _p(s_ws),
+                                      B, T, Cc, _s()), "nvit_som_update")
 
 
 def cos_consistency_fwd(a: Tensor, b: Tensor):

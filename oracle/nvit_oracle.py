@@ -184,17 +184,20 @@ def bmu(x: Tensor, nodes: Tensor) -> Tensor:
     return torch.argmin(torch.cdist(x, nodes, p=2), dim=-1)
 
 
-def som_neighborhood_d2(bmu_loc: Tensor, m: int, n: int) -> Tensor:
-    """squared periodic grid distance of every node to bmu_loc (kohonen.py:80-98): min over the 9 wrapped copies."""
+def som_neighborhood_d2(bmu_loc: Tensor, m: int, n: int, periodic: bool = True) -> Tensor:
+    """squared grid distance of every node to bmu_loc (kohonen.py:80-98): periodic map = min over the 9 wrapped copies,
+    otherwise the plain distance."""
     ii, jj = torch.meshgrid(torch.arange(m), torch.arange(n), indexing="ij")
     loc = torch.stack([ii.reshape(-1), jj.reshape(-1)], dim=1).float()
+    if not periodic:
+        return ((loc - bmu_loc.float()[None, :]) ** 2).sum(-1)
     offs = torch.tensor([[0, 0], [-m, -n], [m, n], [-m, 0], [m, 0], [0, -n], [0, n], [-m, n], [m, -n]]).float()
     d = loc[None, :, :] + offs[:, None, :] - bmu_loc.float()[None, None, :]
     return (d * d).sum(-1).min(dim=0).values
 
 
 @torch.no_grad()
-def som_update_(nodes: Tensor, x: Tensor, idx: Tensor, lr: float, alpha: float) -> None:
+def som_update_(nodes: Tensor, x: Tensor, idx: Tensor, lr: float, alpha: float, periodic: bool = True) -> None:
     """kohonen.py:121-165 literally, including its pairing quirk (SURVEY.md §9.1-Q13): only B iterations;
     iteration i takes the BMU of FLAT token i and the whole image i pooled T*C -> C by means of T consecutive
     elements of the flattened [T, C] buffer; updates are sequential."""
@@ -205,7 +208,7 @@ def som_update_(nodes: Tensor, x: Tensor, idx: Tensor, lr: float, alpha: float) 
     B = x.shape[0]
     for i in range(B):
         w = int(flat_idx[i])
-        d2 = som_neighborhood_d2(torch.tensor([w // n, w % n]), m, n)
+        d2 = som_neighborhood_d2(torch.tensor([w // n, w % n]), m, n, periodic)
         strength = lr * alpha * torch.exp(-d2 / (2 * sigma * sigma))
         v = x[i].reshape(-1)
         sz = v.numel()

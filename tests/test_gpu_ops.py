@@ -581,3 +581,28 @@ def test_normalize_images_input_pipeline():
     f = torch.rand(2, 3, 224, 224, generator=g)
     got = ops.normalize_images(f.to(dev()), 0.5, 0.5)
     assert (got.cpu() - (f - 0.5) / 0.5).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize("periodic", [True, False])
+def test_kohonen_map_update_periodic_and_plain(periodic):
+    """KohonenMap.update_nodes (reference kohonen.py:121-165) on both topologies (kohonen.py:80-98) against the oracle's
+    sequential restatement, plus get_neighborhood_distances and the state_dict keys (`offsets` only when periodic)."""
+    from nvit_amd.kohonen import KohonenMap
+    d = dev()
+    B, T, C, N = 6, 9, 32, 30            # 5 x 6 grid
+    torch.manual_seed(3)
+    km = KohonenMap(C, N, alpha=0.3, periodic=periodic).to(d).train()
+    assert ("offsets" in km.state_dict()) == periodic
+    x = rnd(B, T, C, seed=4)
+    nodes0 = km.nodes.detach().cpu().clone()
+    _, idx = km(x.to(d))
+    ref_idx = torch.cdist(x.reshape(-1, C), nodes0).argmin(dim=-1).reshape(B, T)
+    assert torch.equal(idx.cpu(), ref_idx)
+    km.update_nodes(x.to(d), idx, 0.7)
+    want = nodes0.clone()
+    O.som_update_(want, x, ref_idx, 0.7, 0.3, periodic)
+    assert (km.nodes.detach().cpu() - want).abs().max().item() < 2e-6
+    bmu = torch.tensor([4, 5])
+    got = km.get_neighborhood_distances(bmu.to(d)).cpu()
+    assert torch.equal(got, O.som_neighborhood_d2(bmu, km.m, km.n, periodic))
+    assert got[0].item() == (2.0 if periodic else 41.0)     # node (0,0): wrapped (1,1) away vs (4,5) away
