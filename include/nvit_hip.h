@@ -261,11 +261,12 @@ int nvit_im2col(int dt, const float* img, void* A_l, void* A_g, int B, int ch, i
  * hi + lo on the fly and multiplied on the bf16 MFMA as hi*hi + lo*hi + hi*lo (fp32-accurate to ~2^-16 relative).
  * w_l / w_g: split weight images [C, 2*Kp] from nvit_shadow_weights (perm 2), Kp = nvit_patch_embed_kp(ch*P*P).
  * a_l / a_g: optional bf16 [ceil(M/256)*256, Kp] outputs = the rounded patch rows (columns >= K zero), the saved
- * operand of the weight-gradient GEMM; NULL to skip.  b_l / b_g may be NULL. */
+ * operand of the weight-gradient GEMM; NULL to skip.  lo_l / lo_g: optional bf16 [M, C] twins of out_l / out_g (the
+ * operands of the q and k/v projections; needs C % 8 == 0); NULL to skip.  b_l / b_g may be NULL. */
 int nvit_patch_embed_kp(int K);
-int nvit_patch_embed_fwd(const float* img, const void* w_l, const float* b_l, const float* pos_l, float* out_l, void* a_l,
-                         const void* w_g, const float* b_g, const float* pos_g, float* out_g, void* a_g, int B, int ch,
-                         int S, int Pl, int Pg, int C, void* stream);
+int nvit_patch_embed_fwd(const float* img, const void* w_l, const float* b_l, const float* pos_l, float* out_l, void* lo_l,
+                         void* a_l, const void* w_g, const float* b_g, const float* pos_g, float* out_g, void* lo_g,
+                         void* a_g, int B, int ch, int S, int Pl, int Pg, int C, void* stream);
 /* mean over tokens + LayerNorm(eps) (model.py:455-456, mlp_head.0): x fp32 [B,T,C] ->
  * pooled [B,C] fp32, ln [B,C] fp32 and ln_lo (type dt, ld = C), stats [B,2] = {mean, rstd}. ws [B, nchunk, C]. */
 int nvit_pool_ln_fwd(int dt, const float* x, const float* w, const float* b, float eps, float* pooled, float* ln,

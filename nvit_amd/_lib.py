@@ -62,7 +62,7 @@ SIGNATURES = {
                              _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_im2col": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_patch_embed_kp": [_i],
-    "nvit_patch_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "nvit_patch_embed_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "nvit_pool_ln_fwd": [_i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "nvit_pool_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "nvit_som_bmu": [_vp, _vp, _vp, _i64, _i, _i, _vp, _vp],

@@ -25,6 +25,7 @@ struct PeSide {
   const float* bias;  // [C] or NULL
   const float* pos;   // [T][C]
   float* out;         // [M][C]
+  bf16* out_lo;       // [M][C] bf16 twin of out (the operand of the next GEMM) or NULL
   bf16* a_hi;         // [tiles_m*256][Kp] or NULL
   int P, pad, K, Kp;  // patch edge, reflect pad, patch length ch*P*P and its padding to whole stages
 };
@@ -231,6 +232,10 @@ __global__ __launch_bounds__(512) void patch_embed_kernel(PeArgs g) {
   e.rowadd_period = g.T;
   e.accumulate = 0;
   nt_store_tile_staged<8, float>(e, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wid * 2048);
+  if (sp.out_lo) {
+    e.C = sp.out_lo;
+    nt_store_tile_staged<8, bf16>(e, acc, m0 + wr * 128, n0 + wc * 64, lane, smem + wid * 2048);
+  }
 }
 
 }  // namespace
@@ -239,12 +244,13 @@ __global__ __launch_bounds__(512) void patch_embed_kernel(PeArgs g) {
 extern "C" int nvit_patch_embed_kp(int K) { return (K + 31) / 32 * 32; }
 
 extern "C" int nvit_patch_embed_fwd(const float* img, const void* w_l, const float* b_l, const float* pos_l, float* out_l,
-                                    void* a_l, const void* w_g, const float* b_g, const float* pos_g, float* out_g,
-                                    void* a_g, int B, int ch, int S, int Pl, int Pg, int C, void* stream) {
+                                    void* lo_l, void* a_l, const void* w_g, const float* b_g, const float* pos_g,
+                                    float* out_g, void* lo_g, void* a_g, int B, int ch, int S, int Pl, int Pg, int C,
+                                    void* stream) {
   NVIT_REQUIRE(Pl % 4 == 0 && Pg % 4 == 0 && Pl > 0 && S % Pl == 0 && Pg >= Pl && (Pg - Pl) % 2 == 0,
                "patch_embed: unsupported patch geometry S=%d Pl=%d Pg=%d", S, Pl, Pg);
   NVIT_REQUIRE((Pg - Pl) / 2 < S && S >= 4, "patch_embed: reflect pad must be smaller than the image");
-  NVIT_REQUIRE(C % 4 == 0 && B > 0 && ch > 0, "patch_embed: bad C=%d", C);
+  NVIT_REQUIRE(C % 4 == 0 && B > 0 && ch > 0 && (C % 8 == 0 || (!lo_l && !lo_g)), "patch_embed: bad C=%d", C);
   hipStream_t s = (hipStream_t)stream;
   static bool attr_set = false;
   if (!attr_set) {
@@ -267,11 +273,11 @@ extern "C" int nvit_patch_embed_fwd(const float* img, const void* w_l, const flo
   g.tiles_n = cdiv(C, PE_TN);
   g.mgroups = cdiv(g.tiles_m, 8);
   const int Kl = ch * Pl * Pl, Kg = ch * Pg * Pg;
-  g.side[0] = PeSide{(const char*)w_g, b_g, pos_g, out_g, (bf16*)a_g, Pg, (Pg - Pl) / 2, Kg, nvit_patch_embed_kp(Kg)};
-  g.side[1] = PeSide{(const char*)w_l, b_l, pos_l, out_l, (bf16*)a_l, Pl, 0, Kl, nvit_patch_embed_kp(Kl)};
+  g.side[0] = PeSide{(const char*)w_g, b_g, pos_g, out_g, (bf16*)lo_g, (bf16*)a_g, Pg, (Pg - Pl) / 2, Kg, nvit_patch_embed_kp(Kg)};
+  g.side[1] = PeSide{(const char*)w_l, b_l, pos_l, out_l, (bf16*)lo_l, (bf16*)a_l, Pl, 0, Kl, nvit_patch_embed_kp(Kl)};
   const int grid = 2 * g.mgroups * 8 * g.tiles_n;
   ProfScope ps(NVIT_KID_PATCHIFY, 6.0 * g.M * (double)C * (Kl + Kg),
-               (double)B * ch * S * S * 4.0 + 2.0 * g.M * (double)C * 4.0, s);
+               (double)B * ch * S * S * 4.0 + 2.0 * g.M * (double)C * (lo_l ? 6.0 : 4.0), s);
   if (((Pg - Pl) / 2) % 4 == 0 && S % 4 == 0)
     hipLaunchKernelGGL(patch_embed_kernel<true>, dim3(grid), dim3(512), PE_LDS, s, g);
   else

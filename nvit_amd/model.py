@@ -383,7 +383,7 @@ class _CrossFn(torch.autograd.Function):
     """CrossAttentionBlock.forward (reference model.py:219-275), nViT branch."""
 
     @staticmethod
-    def forward(ctx, loc, glo, rt, impl, attn_alpha, sqk, wq, wk, wv, wproj, wout, bq, bk_, bv, bproj, bout):
+    def forward(ctx, loc, glo, loc_lo, glo_lo, rt, impl, attn_alpha, sqk, wq, wk, wv, wproj, wout, bq, bk_, bv, bproj, bout):
         cfg = rt.model.config
         C, H = cfg.n_embd, cfg.n_head
         d = C // H
@@ -396,8 +396,9 @@ class _CrossFn(torch.autograd.Function):
         has_b = bq is not None
         if dt == F32:
             loc_lo, glo_lo = loc, glo
-        else:
-            loc_lo, glo_lo = ops.cast(loc, dt), ops.cast(glo, dt)
+        else:   # bf16 operand copies: handed in by the producer (patch-embedding epilogue) or cast here
+            loc_lo = ops.cast(loc, dt) if loc_lo is None else loc_lo
+            glo_lo = ops.cast(glo, dt) if glo_lo is None else glo_lo
         if not has_b and d == 64 and ops.fusable(dt, M, C, C):
             bufs = ops.qk_buffers(dt, B, T, H, d, loc.device)
             ops.gemm_nt_qknorm(loc_lo, sh["x.q.W"], M, C, 1, 0, sqk, c_q, B, T, H, d, bufs)
@@ -434,7 +435,7 @@ class _CrossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx, _unused):
         if dx is None:
-            return (None,) * 16
+            return (None,) * 18
         loc, glo, loc_lo, glo_lo, qh, kh, vh, rq, rk, o, lse, pr, g, y, attn_alpha, sqk = ctx.saved_tensors
         rt, impl = ctx.rt, ctx.impl
         B, T, C, H, d, M = ctx.dims
@@ -479,7 +480,7 @@ class _CrossFn(torch.autograd.Function):
             gbk, gbv = g_bkv[:C], g_bkv[C:]
         else:
             g_bq = gbk = gbv = None
-        return (dloc, dglo, None, None, d_alpha, d_sqk, g_wq, g_wkv[:C], g_wkv[C:], g_wproj, g_wout, g_bq, gbk, gbv,
+        return (dloc, dglo, None, None, None, None, d_alpha, d_sqk, g_wq, g_wkv[:C], g_wkv[C:], g_wproj, g_wout, g_bq, gbk, gbv,
                 g_bproj, g_bout)
 
 
@@ -510,17 +511,21 @@ class _EmbedFn(torch.autograd.Function):
             glo = ops.gemm_nt(A_g, rt.sh["pe_g"], M, C, Kg, bias=bg, rowadd=posg.reshape(T, C), rowadd_period=T)
         else:
             # (the split weight images are part of the shadow set, built by nvit_shadow_weights)
-            loc, glo, A_l, A_g = ops.patch_embed_fwd(img, rt.sh["pe_l"], bl, posl.reshape(T, C), rt.sh["pe_g"], bg,
-                                                     posg.reshape(T, C), Pl, Pg, C)
+            loc, glo, A_l, A_g, loc_lo, glo_lo = ops.patch_embed_fwd(img, rt.sh["pe_l"], bl, posl.reshape(T, C),
+                                                                     rt.sh["pe_g"], bg, posg.reshape(T, C), Pl, Pg, C,
+                                                                     twins=(C % 8 == 0))
         ctx.rt = rt
         ctx.dims = (B, T, C, M, Kl, Kg)
         ctx.par = (wl, wg)
         ctx.shapes = (wl.shape, wg.shape, posl.shape)
         ctx.save_for_backward(A_l, A_g)
-        return loc, glo
+        if rt.dt == F32 or loc_lo is None:
+            loc_lo, glo_lo = loc.new_empty(0), loc.new_empty(0)
+        ctx.mark_non_differentiable(loc_lo, glo_lo)
+        return loc, glo, loc_lo, glo_lo
 
     @staticmethod
-    def backward(ctx, dloc, dglo):
+    def backward(ctx, dloc, dglo, _lo1, _lo2):
         A_l, A_g = ctx.saved_tensors   # bf16 mode: [Mpad, Kp] patch rows written by the fused forward kernel
         rt = ctx.rt
         B, T, C, M, Kl, Kg = ctx.dims
@@ -755,9 +760,9 @@ class CrossAttentionBlock(nn.Module):
                 self.proj.weight, self.out_proj.weight, b(self.q_local), b(self.k_global), b(self.v_global),
                 b(self.proj), b(self.out_proj))
 
-    def _run(self, loc: Tensor, glo: Tensor):
+    def _run(self, loc: Tensor, glo: Tensor, loc_lo: Optional[Tensor] = None, glo_lo: Optional[Tensor] = None):
         model = self._owner
-        x, x_lo = _CrossFn.apply(loc, glo, model._rt, model._attn_impl(), *self._args())
+        x, x_lo = _CrossFn.apply(loc, glo, loc_lo, glo_lo, model._rt, model._attn_impl(), *self._args())
         return x, _lo(model._rt, x, x_lo)
 
     def forward(self, local: Tensor, global_: Tensor) -> Tensor:
@@ -954,9 +959,11 @@ class ViT(nn.Module):
         B = img.shape[0]
         T, C = self.n_tokens, cfg.n_embd
         img = img.contiguous().float()
-        loc, glo = _EmbedFn.apply(img, rt, self.local_patch_embed.weight, self.local_patch_embed.bias,
-                                  self.local_pos_embed, self.global_patch_embed[1].weight,
-                                  self.global_patch_embed[1].bias, self.global_pos_embed)
+        loc, glo, loc_lo, glo_lo = _EmbedFn.apply(img, rt, self.local_patch_embed.weight, self.local_patch_embed.bias,
+                                                  self.local_pos_embed, self.global_patch_embed[1].weight,
+                                                  self.global_patch_embed[1].bias, self.global_pos_embed)
+        if loc_lo.numel() == 0:   # fp32 mode (or an embedding width the twin store does not cover): no bf16 copies
+            loc_lo = glo_lo = None
         aux: Dict[str, Tensor] = {}
         if cfg.use_kohonen:
             # reference model.py:419-444
@@ -970,15 +977,15 @@ class ViT(nn.Module):
                 if self._node_sync is not None:   # data parallel: keep the SOM replicas identical
                     self._node_sync(self.local_kohonen.nodes.data, self.global_kohonen.nodes.data)
             lrep2, grep2 = local_repr.reshape(B * T, C), global_repr.reshape(B * T, C)
-            local_new, _ = self.cross_attention._run(lrep2, loc)
-            global_new, _ = self.cross_attention._run(grep2, glo)
+            local_new, _ = self.cross_attention._run(lrep2, loc, None, loc_lo)
+            global_new, _ = self.cross_attention._run(grep2, glo, None, glo_lo)
             aux["kohonen_consistency"] = self.compute_consistency_loss(local_repr, global_repr)
             aux["kohonen_smoothness"] = self.compute_smoothness_loss(local_idx, global_idx)
             aux["local_quantization"] = HuberFn.apply(lrep2, loc)
             aux["global_quantization"] = HuberFn.apply(grep2, glo)
             x, x_lo = self.cross_attention._run(local_new, global_new)
         else:
-            x, x_lo = self.cross_attention._run(loc, glo)
+            x, x_lo = self.cross_attention._run(loc, glo, loc_lo, glo_lo)
         taps = self._taps
         if taps is not None:
             taps["loc"], taps["glo"], taps["x0"] = loc.detach(), glo.detach(), x.detach()

@@ -392,9 +392,10 @@ def patch_kp(K: int) -> int:
 
 
 def patch_embed_fwd(img: Tensor, w_l: Tensor, b_l: Optional[Tensor], pos_l: Tensor, w_g: Tensor, b_g: Optional[Tensor],
-                    pos_g: Tensor, Pl: int, Pg: int, Cc: int, save_rows: bool = True):
-    """Fused dual patch embedding of the bf16 mode -> loc, glo fp32 [M, C] and (save_rows) the bf16 patch rows
-    a_l [Mpad, Kp_l], a_g [Mpad, Kp_g] for the weight gradients.  w_l / w_g: split images [C, 2*Kp] (shadow perm 2)."""
+                    pos_g: Tensor, Pl: int, Pg: int, Cc: int, save_rows: bool = True, twins: bool = False):
+    """Fused dual patch embedding of the bf16 mode -> loc, glo fp32 [M, C], (twins) their bf16 copies, and (save_rows)
+    the bf16 patch rows a_l [Mpad, Kp_l], a_g [Mpad, Kp_g] for the weight gradients.
+    w_l / w_g: split images [C, 2*Kp] (shadow perm 2).  Returns (loc, glo, a_l, a_g, loc_lo, glo_lo)."""
     B, ch, S, _ = img.shape
     T = (S // Pl) ** 2
     M = B * T
@@ -405,15 +406,18 @@ def patch_embed_fwd(img: Tensor, w_l: Tensor, b_l: Optional[Tensor], pos_l: Tens
     dev = img.device
     loc = torch.empty((M, Cc), device=dev, dtype=torch.float32)
     glo = torch.empty((M, Cc), device=dev, dtype=torch.float32)
-    a_l = a_g = None
+    a_l = a_g = lo_l = lo_g = None
     if save_rows:
         Mpad = round_up(M, 256)
         a_l = torch.empty((Mpad, Kpl), device=dev, dtype=torch.bfloat16)
         a_g = torch.empty((Mpad, Kpg), device=dev, dtype=torch.bfloat16)
-    check(_lib.load().nvit_patch_embed_fwd(_p(img), _p(w_l), _p(b_l), _p(pos_l), _p(loc), _p(a_l), _p(w_g), _p(b_g),
-                                           _p(pos_g), _p(glo), _p(a_g), B, ch, S, Pl, Pg, Cc, _s()),
+    if twins:
+        lo_l = torch.empty((M, Cc), device=dev, dtype=torch.bfloat16)
+        lo_g = torch.empty((M, Cc), device=dev, dtype=torch.bfloat16)
+    check(_lib.load().nvit_patch_embed_fwd(_p(img), _p(w_l), _p(b_l), _p(pos_l), _p(loc), _p(lo_l), _p(a_l), _p(w_g),
+                                           _p(b_g), _p(pos_g), _p(glo), _p(lo_g), _p(a_g), B, ch, S, Pl, Pg, Cc, _s()),
           "nvit_patch_embed_fwd")
-    return loc, glo, a_l, a_g
+    return loc, glo, a_l, a_g, lo_l, lo_g
 
 
 def pool_ln_fwd(dt: int, x: Tensor, w: Tensor, b: Tensor, eps: float, B: int, T: int, Cc: int):

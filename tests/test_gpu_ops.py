@@ -163,7 +163,10 @@ def test_fused_patch_embed(B, ch, S, Pl, Pg, C):
         ent.append((w.to(d), sh[-1], 2 * Kp, K, None, 0, 0, 2))
     t, n = ops.shadow_table(ent, d)
     ops.shadow_weights(t, n, BF16)
-    loc, glo, a_l, a_g = ops.patch_embed_fwd(img.to(d), sh[0], bl.to(d), pl.to(d), sh[1], bg.to(d), pg.to(d), Pl, Pg, C)
+    loc, glo, a_l, a_g, lo_l, lo_g = ops.patch_embed_fwd(img.to(d), sh[0], bl.to(d), pl.to(d), sh[1], bg.to(d), pg.to(d),
+                                                         Pl, Pg, C, twins=True)
+    # the bf16 twins are the rounded fp32 outputs, bit for bit
+    assert torch.equal(lo_l.cpu(), loc.cpu().bfloat16()) and torch.equal(lo_g.cpu(), glo.cpu().bfloat16())
     Al = O.im2col(img, Pl, Pl, 0).reshape(M, Kl)
     Ag = O.im2col(img, Pg, Pl, (Pg - Pl) // 2).reshape(M, Kg)
     for out, A, w, b, pos, a_hi, K in ((loc, Al, wl, bl, pl, a_l, Kl), (glo, Ag, wg, bg, pg, a_g, Kg)):
@@ -175,8 +178,9 @@ def test_fused_patch_embed(B, ch, S, Pl, Pg, C):
         assert torch.equal(rows[:, :K].float(), A.bfloat16().float())
         assert torch.equal(rows[:, K:].float(), torch.zeros(M, rows.shape[1] - K))
     # without bias and without the saved rows
-    loc2, glo2, a2, _ = ops.patch_embed_fwd(img.to(d), sh[0], None, pl.to(d), sh[1], None, pg.to(d), Pl, Pg, C, save_rows=False)
-    assert a2 is None
+    loc2, glo2, a2, _, lo2, _ = ops.patch_embed_fwd(img.to(d), sh[0], None, pl.to(d), sh[1], None, pg.to(d), Pl, Pg, C,
+                                                    save_rows=False)
+    assert a2 is None and lo2 is None
     assert (loc2.cpu() + bl - loc.cpu()).abs().max().item() < 1e-6 and (glo2.cpu() + bg - glo.cpu()).abs().max().item() < 1e-6
 
 

@@ -130,7 +130,7 @@ def check_all(B: int = 128, T: int = 784, C: int = 768, H: int = 12, verbose: bo
             ws.append(w)
         b_l, b_g = (_rnd((C,), s_, dev, scale=0.1, dtype=torch.float32) for s_ in (19, 20))
         p_l, p_g = (_rnd((T, C), s_, dev, scale=0.02, dtype=torch.float32) for s_ in (24, 25))
-        loc, glo, a_l, a_g = ops.patch_embed_fwd(img, sh[0], b_l, p_l, sh[1], b_g, p_g, Pl, Pg, C)
+        loc, glo, a_l, a_g, lo_l, lo_g = ops.patch_embed_fwd(img, sh[0], b_l, p_l, sh[1], b_g, p_g, Pl, Pg, C, twins=True)
         A_l = Fn.unfold(img, Pl, stride=Pl).transpose(1, 2).reshape(M, -1)[rows]
         A_g = Fn.unfold(Fn.pad(img, (pad,) * 4, mode="reflect"), Pg, stride=Pl).transpose(1, 2).reshape(M, -1)[rows]
         for name, out, A, w, b, pos, a_hi in (("local", loc, A_l, ws[0], b_l, p_l, a_l), ("global", glo, A_g, ws[1], b_g, p_g, a_g)):
@@ -139,7 +139,10 @@ def check_all(B: int = 128, T: int = 784, C: int = 768, H: int = 12, verbose: bo
             rep.add(f"patch_embed {name} M={M} K={A.shape[1]} (fused gather, hi/lo split)", err, 1e-5 * max(1.0, ref.abs().max().item()))
             e_rows = (a_hi[rows][:, :A.shape[1]].float() - A.to(bf).float()).abs().max().item()
             rep.add(f"patch_embed {name} saved bf16 patch rows (exact)", e_rows, 1e-30)
-        del img, loc, glo, a_l, a_g, A_l, A_g, sh, ws
+        e_tw = max((lo_l[rows].float() - loc[rows].to(bf).float()).abs().max().item(),
+                   (lo_g[rows].float() - glo[rows].to(bf).float()).abs().max().item())
+        rep.add("patch_embed bf16 twins of the outputs (exact)", e_tw, 1e-30)
+        del img, loc, glo, a_l, a_g, lo_l, lo_g, A_l, A_g, sh, ws
 
     # ---------------------------------------------------------------- EPI 3: SwiGLU forward (c_fc, cross proj)
     for F, use_gs in ((4 * C, True), (C, False)):
