@@ -147,9 +147,11 @@ int nvit_gemm_nt_swiglu_bwd(int dt, const void* A, int lda, const void* B, int l
                             float* part, int M, int F, int K, const float* gs, float gscale, void* stream);
 int nvit_gemm_nt_swiglu(int dt, const void* A, int lda, const void* B, int ldb, void* uv, void* xm, int M, int F,
                         int K, const float* gs, float gscale, void* stream);
+/* q_prescale: extra factor folded into the q part (qh = q_prescale * sqk*c_q * unit vector, one rounding); pass the same
+ * value to nvit_attn_fwd_bounded / nvit_attn_bwd_qknorm.  1 = plain. */
 int nvit_gemm_nt_qknorm(int dt, const void* A, int lda, const void* B, int ldb, int M, int K, int nparts, int part0,
-                        const float* sqk, float c_q, void* qh, void* kh, void* vh, float* rq, float* rk, int T, int H,
-                        int d, void* stream);
+                        const float* sqk, float c_q, float q_prescale, void* qh, void* kh, void* vh, float* rq, float* rk,
+                        int T, int H, int d, void* stream);
 
 /* nvit_gemm_tn: weight gradient  G[N,K] (+)= sum_m A[m,N-col] * B[m,K-col]  over Mred rows.
  * A [Mred, N] (lda), B [Mred, K] (ldb) of type dt.  Split over `splits` row chunks into the
@@ -232,21 +234,27 @@ int nvit_attn_fwd(int dt, int impl, const void* qh, const void* kh, const void* 
                   int B, int H, int Tq, int Tk, int d, void* stream);
 /* Same, for the nViT call sites where q and k are (sqk*c_q) * unit vectors per head (model.py:108-112): every score is
  * bounded by max_d (sqk_d*c_q)^2, and while that bound is small (it is 1 at initialisation) the MFMA kernel takes
- * probabilities relative to the bound instead of a running maximum (no per-tile max / rescale).  sqk: [H*d] fp32. */
+ * probabilities relative to the bound instead of a running maximum (no per-tile max / rescale).  sqk: [H*d] fp32.
+ * q_prescale > 0: qh holds q_prescale * q_hat (see nvit_gemm_nt_qknorm); the result is that of the un-scaled q.  With
+ * q_prescale = scale * log2(e) the exponent of the MFMA kernel needs no multiply: the score accumulator starts at minus
+ * the bound and goes straight into v_exp_f32 (one VALU instruction less per score in a VALU-bound kernel). */
 int nvit_attn_fwd_bounded(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, const float* sqk,
-                          float c_q, void* o, float* lse, int B, int H, int Tq, int Tk, int d, void* stream);
-/* delta: [2,B,H,Tq] fp32 workspace (rowsum(dO*O), and lse in log2 units for the dk/dv kernel). dqh,dkh,dvh [B,H,T,d] type dt. */
+                          float c_q, float q_prescale, void* o, float* lse, int B, int H, int Tq, int Tk, int d,
+                          void* stream);
+/* delta: [2,B,H,Tq] fp32 workspace (rowsum(dO*O), and MINUS lse in log2 units - an accumulator seed of the dk/dv
+ * kernel). dqh,dkh,dvh [B,H,T,d] type dt. */
 int nvit_attn_bwd(int dt, int impl, const void* dout, const void* qh, const void* kh, const void* vh, const void* o,
                   const float* lse, float scale, void* dqh, void* dkh, void* dvh, float* delta, int B, int H,
                   int Tq, int Tk, int d, void* stream);
 
 /* nvit_attn_bwd_qknorm: MFMA attention backward (bf16, d=64) with nvit_qknorm_bwd fused into the epilogues:
  * writes token-major dq/dk/dv (type bf16, row stride ld elements, head h at column h*64) and the partial sums
- * part_q [B*ceil(Tq/128), C], part_k [B*ceil(Tk/128), C] of d/d(sqk*c_q) (reduce with nvit_colsum_reduce). */
+ * part_q [B*ceil(Tq/128), C], part_k [B*ceil(Tk/128), C] of d/d(sqk*c_q) (reduce with nvit_colsum_reduce).
+ * q_prescale: the factor the producer folded into qh (see nvit_attn_fwd_bounded); gradients are those of the plain form. */
 int nvit_attn_bwd_qknorm(int dt, const void* dout, const void* qh, const void* kh, const void* vh, const void* o,
                          const float* lse, float scale, const float* rq, const float* rk, const float* sqk, float c_q,
-                         void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q, float* part_k, float* delta, int B, int H,
-                         int Tq, int Tk, int d, void* stream);
+                         float q_prescale, void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q, float* part_k,
+                         float* delta, int B, int H, int Tq, int Tk, int d, void* stream);
 
 /* ---- patch embedding / head / reconstruction -------------------------------------------
  * nvit_im2col: A_l [M, ch*Pl*Pl] and A_g [M, ch*Pg*Pg] (type dt, column order (c,ph,pw)) from

@@ -39,7 +39,7 @@ SIGNATURES = {
     "nvit_gemm_nt_fusable": [_i, _i, _i, _i],
     "nvit_gemm_nt_swiglu": [_i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp, _f, _vp],
     "nvit_gemm_nt_swiglu_bwd": [_i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _vp],
-    "nvit_gemm_nt_qknorm": [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "nvit_gemm_nt_qknorm": [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "nvit_gemm_tn": [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i64, _i, _i, _vp],
     "nvit_lerp_fwd": [_i, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "nvit_lerp_bwd": [_i, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -56,9 +56,9 @@ SIGNATURES = {
     "nvit_normalize_images": [_vp, _i, _vp, _i, _i, _i, _i, _f, _f, _vp],
     "nvit_scale_cols": [_vp, _i, _vp, _f, _vp, _i, _i, _i, _i, _vp],
     "nvit_attn_fwd": [_i, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "nvit_attn_fwd_bounded": [_i, _i, _vp, _vp, _vp, _f, _vp, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "nvit_attn_fwd_bounded": [_i, _i, _vp, _vp, _vp, _f, _vp, _f, _f, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_attn_bwd": [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "nvit_attn_bwd_qknorm": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _vp, _vp,
+    "nvit_attn_bwd_qknorm": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _f, _f, _vp, _i, _vp, _vp, _i, _vp, _vp,
                              _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_im2col": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "nvit_patch_embed_kp": [_i],

@@ -108,10 +108,15 @@ __device__ __forceinline__ void store_tile32x64(const f32x4 (&g)[4][2], char* sc
 __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsigned lds_off) {
   unsigned keep;
   const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_off);
+  // (the base is wave-uniform by construction; readfirstlane folds away when the compiler can see that, and keeps the
+  //  "s" constraint satisfiable when it cannot - e.g. a pointer captured by reference in a lambda it did not dissolve)
+  const unsigned long long ub = (unsigned long long)(uintptr_t)sbase;
+  const unsigned long long sb = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ub) |
+                                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ub >> 32)) << 32);
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
       : "=&s"(keep)
-      : "v"(voff), "s"(sbase), "s"(m)
+      : "v"(voff), "s"(sb), "s"(m)
       : "memory");
 }
 // DMA one 64-row tile of `src` (row stride ld_bytes, rows clamped to nrows-1) to LDS byte offset tile_off;
@@ -174,7 +179,7 @@ __device__ __forceinline__ void work_of(int ntile, int& bh, int& tile) {
 constexpr float BOUND_MAX = 60.0f;   // in log2 units: exp2(-2*60) is still a normal fp32 / bf16 number
 
 __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __restrict__ qh, const bf16* __restrict__ kh,
-                                                             const bf16* __restrict__ vh, float scale,
+                                                             const bf16* __restrict__ vh, float scale, float qpre,
                                                              const float* __restrict__ sqk, float c_q,
                                                              bf16* __restrict__ o, float* __restrict__ lse, int H,
                                                              int Tq, int Tk) {
@@ -187,7 +192,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
   const int q0 = tile_ * 128 + wid * 32;
   const bf16* kbase = kh + (size_t)bh * Tk * D;
   const bf16* vbase = vh + (size_t)bh * Tk * D;
-  const float c2 = scale * LOG2E;
+  // qh holds qpre * q_hat (the producer folds the factor into the learned scale, one rounding): the MFMA result times
+  // c2 is the score in log2 units.  qpre = scale * log2(e) makes c2 exactly 1 (UNIT): the fast path then needs no
+  // multiply at all - the accumulator starts at -bound and goes straight into v_exp_f32.
+  const float c2t = scale * LOG2E;
+  const float c2 = c2t / qpre;
+  const bool unit = __builtin_amdgcn_readfirstlane(fabsf(c2 - 1.0f) < 1e-6f ? 1 : 0) != 0;
 
   uint4 qf[2][2];
   f32x4 oacc[4][2];
@@ -202,7 +212,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
     float sm = fabsf(sqk[h * D + lane] * c_q);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sm = fmaxf(sm, __shfl_xor(sm, off, 64));
-    tb = c2 * sm * sm;
+    tb = c2t * sm * sm;
   }
   const bool fast = __builtin_amdgcn_readfirstlane(tb <= BOUND_MAX ? 1 : 0) != 0;
   f32x4 lacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};   // fast path: row sums from the MFMA pipe
@@ -238,9 +248,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
   // K/V ring and the barriers (wave_active), and the ragged last KV tile - peeled, so the steady-state tiles spend no
   // VALU on masks - multiplies and exponentiates only its valid 16-key fragments (nkf) / 32-key MFMA steps (ns2).
   const bool wave_active = q0 < Tq;
-  auto tile_body = [&](const int t, auto masked_, auto fast_) {
+  f32x4 ntb = {-tb, -tb, -tb, -tb};   // UNIT: initial accumulator of the score product
+  asm volatile("" : "+v"(ntb));
+  auto tile_body = [&](const int t, auto masked_, auto fast_, auto unit_) {
     constexpr bool MASKED = decltype(masked_)::value;
     constexpr bool FAST = decltype(fast_)::value;
+    constexpr bool UNIT = decltype(unit_)::value;
     if (t + 2 < nt) {
       const int sl = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
       tile_dma(kbase, ROWB, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid, voff);
@@ -262,12 +275,12 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
             const uint4 a0 = row_frag(kt, kf * 16, 0, l15, lg), a1 = row_frag(kt, kf * 16, 1, l15, lg);
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-              f32x4 z = {0.f, 0.f, 0.f, 0.f};
+              f32x4 z = UNIT ? ntb : (f32x4){0.f, 0.f, 0.f, 0.f};
               z = mfma16(a0, qf[f][0], z);
               z = mfma16(a1, qf[f][1], z);
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                float p = fast_exp2(z[r] * c2 - tb);
+                float p = UNIT ? fast_exp2(z[r]) : fast_exp2(z[r] * c2 - tb);
                 if (MASKED && kf * 16 + lg * 4 + r >= nvalid) p = 0.f;
                 p_[kk][f][r] = p;
               }
@@ -376,19 +389,23 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
     __syncthreads();
     cur = cur == 2 ? 0 : cur + 1;
   };
-  if (fast) {
-    for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{}, std::true_type{});
-    if (Tk % TKV)
-      tile_body(nt - 1, std::true_type{}, std::true_type{});
-    else
-      tile_body(nt - 1, std::false_type{}, std::true_type{});
-  } else {
-    for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{}, std::false_type{});
-    if (Tk % TKV)
-      tile_body(nt - 1, std::true_type{}, std::false_type{});
-    else
-      tile_body(nt - 1, std::false_type{}, std::false_type{});
+  // (spelled out: wrapping the three variants in a second generic lambda keeps hipcc from dissolving the captures, and
+  //  the accumulators end up in scratch memory)
+#define NVIT_RUN_TILES(FAST_, UNIT_)                                                            \
+  {                                                                                             \
+    for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{}, FAST_{}, UNIT_{});         \
+    if (Tk % TKV)                                                                               \
+      tile_body(nt - 1, std::true_type{}, FAST_{}, UNIT_{});                                    \
+    else                                                                                        \
+      tile_body(nt - 1, std::false_type{}, FAST_{}, UNIT_{});                                   \
   }
+  if (fast && unit)
+    NVIT_RUN_TILES(std::true_type, std::true_type)
+  else if (fast)
+    NVIT_RUN_TILES(std::true_type, std::false_type)
+  else
+    NVIT_RUN_TILES(std::false_type, std::false_type)
+#undef NVIT_RUN_TILES
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     float l, lse_v;
@@ -399,7 +416,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
       l = l_[f];
       l += __shfl_xor(l, 16, 64);
       l += __shfl_xor(l, 32, 64);
-      lse_v = m_[f] * scale + logf(l);
+      lse_v = m_[f] * (c2 * (1.0f / LOG2E)) + logf(l);   // m_ is in units of the (pre-scaled) MFMA result
     }
     const int q = q0 + 16 * f + l15;
     const float inv = 1.0f / l;
@@ -423,6 +440,7 @@ struct QkFuse {
   bf16* out_v;        // (dk/dv kernel only) same for the value projection
   int ld;
   float* part;        // [B * gridDim.x, C]
+  float xs;           // the saved x_hat rows carry an extra factor 1/xs (pre-scaled q): multiply by xs before use
 };
 
 __device__ __forceinline__ void qk_bwd_epilogue(f32x4 (&g)[4][2], const bf16* xh_bh, const QkFuse& fu, int row0, int T,
@@ -449,7 +467,7 @@ __device__ __forceinline__ void qk_bwd_epilogue(f32x4 (&g)[4][2], const bf16* xh
     s[df] = *reinterpret_cast<const f32x4*>(fu.sqk + h * 64 + df * 16 + 4 * lg) * fu.c_q;
     ds[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int e = 0; e < 4; ++e) sinv[df][e] = s[df][e] != 0.f ? __builtin_amdgcn_rcpf(s[df][e]) : 0.f;   // 1 ulp, 1 instruction
+    for (int e = 0; e < 4; ++e) sinv[df][e] = s[df][e] != 0.f ? __builtin_amdgcn_rcpf(s[df][e]) * fu.xs : 0.f;   // 1 ulp
   }
   f32x4 outv[4][2];
 #pragma unroll
@@ -497,8 +515,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
                                                                 const bf16* __restrict__ kh, const bf16* __restrict__ vh,
                                                                 const float* __restrict__ lse,
                                                                 const bf16* __restrict__ og, float* __restrict__ delta,
-                                                                float scale, bf16* __restrict__ dqh, int H, int Tq,
-                                                                int Tk, QkFuse fu) {
+                                                                float scale, float qpre, bf16* __restrict__ dqh, int H,
+                                                                int Tq, int Tk, QkFuse fu) {
   // This kernel also produces delta[bh][q] = <dO_q, O_q> (the softmax-backward row term) from the attention output `og`
   // (token-major like dout) and stores it, with lse in log2 units, in the [2,B,H,Tq] side buffer for the dk/dv kernel,
   // which runs after it.  (og == NULL: delta is an input and no side buffer is written - not used by the launchers.)
@@ -511,7 +529,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
   const int q0 = tile_ * 128 + wid * 32;
   const bf16* kbase = kh + (size_t)bh * Tk * D;
   const bf16* vbase = vh + (size_t)bh * Tk * D;
-  const float c2 = scale * LOG2E;
+  const float c2 = scale * LOG2E / qpre;   // see the forward kernel: 1 when q was pre-scaled by scale * log2(e)
+  const bool unit = __builtin_amdgcn_readfirstlane(fabsf(c2 - 1.0f) < 1e-6f ? 1 : 0) != 0;
 
   uint4 qf[2][2], gf[2][2];
   float lse2[2], dl[2];
@@ -549,9 +568,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
       part += __shfl_xor(part, 32, 64);
       dl[f] = part;
       if (lg == 0 && qu < Tq) {
-        // side buffer for the dk/dv kernel (runs after this one): delta, and lse already in log2 units
+        // side buffer for the dk/dv kernel (runs after this one): delta, and -lse in log2 units (an accumulator seed)
         delta[(size_t)bh * Tq + qu] = part;
-        delta[((size_t)(gridDim.x / ((Tq + 127) / 128)) + bh) * Tq + qu] = lse2[f];
+        delta[((size_t)(gridDim.x / ((Tq + 127) / 128)) + bh) * Tq + qu] = -lse2[f];
       }
     } else {
       dl[f] = delta[(size_t)bh * Tq + q];
@@ -575,16 +594,19 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   // -delta as the initial accumulator of the dP product: loop-invariant register quads (passed as the MFMA's C operand)
-  f32x4 ndl[2];
+  f32x4 ndl[2], nls[2];   // nls (UNIT): -lse as the initial accumulator of the score product
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     ndl[f] = (f32x4){-dl[f], -dl[f], -dl[f], -dl[f]};
+    nls[f] = (f32x4){-lse2[f], -lse2[f], -lse2[f], -lse2[f]};
     asm volatile("" : "+v"(ndl[f]));
+    asm volatile("" : "+v"(nls[f]));
   }
   int cur = 0;
   const bool wave_active = q0 < Tq;   // see the forward kernel
-  auto tile_body = [&](const int t, auto masked_) {
+  auto tile_body = [&](const int t, auto masked_, auto unit_) {
     constexpr bool MASKED = decltype(masked_)::value;
+    constexpr bool UNIT = decltype(unit_)::value;
     if (t + 2 < nt) {
       const int sl = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
       tile_dma(kbase, ROWB, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid, voff);
@@ -609,15 +631,15 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
               const uint4 v0 = row_frag(vt, kf * 16, 0, l15, lg), v1 = row_frag(vt, kf * 16, 1, l15, lg);
 #pragma unroll
               for (int f = 0; f < 2; ++f) {
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                f32x4 z = UNIT ? nls[f] : (f32x4){0.f, 0.f, 0.f, 0.f};
                 z = mfma16(a0, qf[f][0], z);
-                z = mfma16(a1, qf[f][1], z);  // S^T
+                z = mfma16(a1, qf[f][1], z);  // S^T (UNIT: already minus lse, in log2 units)
                 f32x4 w = mfma16(v0, gf[f][0], ndl[f]);        // row constant -delta as the initial accumulator
                 w = mfma16(v1, gf[f][1], w);  // dP^T - delta
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                   const bool valid = !MASKED || (kf * 16 + lg * 4 + r) < nvalid;
-                  const float p = valid ? fast_exp2(z[r] * c2 - lse2[f]) : 0.f;
+                  const float p = valid ? (UNIT ? fast_exp2(z[r]) : fast_exp2(z[r] * c2 - lse2[f])) : 0.f;
                   ds_[kk][f][r] = p * w[r];   // the softmax scale is applied once, to the dQ accumulators
                 }
               }
@@ -648,15 +670,23 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
     __syncthreads();
     cur = cur == 2 ? 0 : cur + 1;
   };
-  for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{});
-  if (Tk % TKV)
-    tile_body(nt - 1, std::true_type{});
+#define NVIT_RUN_TILES(UNIT_)                                                          \
+  {                                                                                    \
+    for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{}, UNIT_{});         \
+    if (Tk % TKV)                                                                      \
+      tile_body(nt - 1, std::true_type{}, UNIT_{});                                    \
+    else                                                                               \
+      tile_body(nt - 1, std::false_type{}, UNIT_{});                                   \
+  }
+  if (unit)
+    NVIT_RUN_TILES(std::true_type)
   else
-    tile_body(nt - 1, std::false_type{});
+    NVIT_RUN_TILES(std::false_type)
+#undef NVIT_RUN_TILES
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int f = 0; f < 2; ++f) dq[i][f] = dq[i][f] * scale;
+    for (int f = 0; f < 2; ++f) dq[i][f] = dq[i][f] * scale;   // d/d(q_hat): K is not pre-scaled
   if constexpr (FUSE) {
     qk_bwd_epilogue(dq, qh + (size_t)bh * Tq * D, fu, q0, Tq, H, b, h, lane, wid, &lds[0][0][0], tile_, (Tq + 127) / 128);
   } else {
@@ -690,8 +720,9 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
                                                                  const bf16* __restrict__ kh, const bf16* __restrict__ vh,
                                                                  const float* __restrict__ lse,
                                                                  const float* __restrict__ delta, float scale,
-                                                                 bf16* __restrict__ dkh, bf16* __restrict__ dvh, int H,
-                                                                 int Tq, int Tk, QkFuse fu) {
+                                                                 float qpre, bf16* __restrict__ dkh,
+                                                                 bf16* __restrict__ dvh, int H, int Tq, int Tk,
+                                                                 QkFuse fu) {
   __shared__ __attribute__((aligned(16))) char lds[3 * DKV_SLOT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -703,8 +734,9 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
   const bf16* qbase = qh + (size_t)bh * Tq * D;
   const bf16* gbase = dout + (size_t)b * Tq * (H * D) + h * D;
   const float* dbase = delta + (size_t)bh * Tq;
-  const float* lbase = delta + ((size_t)(gridDim.x / ((Tk + 127) / 128)) + bh) * Tq;   // lse * log2(e), written by the dq kernel
-  const float c2 = scale * LOG2E;
+  const float* lbase = delta + ((size_t)(gridDim.x / ((Tk + 127) / 128)) + bh) * Tq;   // -lse * log2(e), written by the dq kernel
+  const float c2 = scale * LOG2E / qpre;   // see the forward kernel
+  const bool unit = __builtin_amdgcn_readfirstlane(fabsf(c2 - 1.0f) < 1e-6f ? 1 : 0) != 0;
   const int nt = (Tq + TKV - 1) / TKV;
   const unsigned ring = lds_addr(&lds[0]);
 
@@ -754,8 +786,9 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
     }
   const bool wave_active = k0 < Tk;   // a wave whose 32 keys all lie past Tk only feeds the ring and the barriers
   int cur = 0;
-  auto tile_body = [&](const int t, auto masked_) {
+  auto tile_body = [&](const int t, auto masked_, auto unit_) {
     constexpr bool MASKED = decltype(masked_)::value;
+    constexpr bool UNIT = decltype(unit_)::value;
     if (t + 2 < nt) tile_issue(t + 2, cur == 0 ? 2 : cur - 1);
     if (wave_active) {
       const char* qt = &lds[cur * DKV_SLOT];
@@ -773,20 +806,21 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
           if (!MASKED || qfi < nqf) {
             const uint4 a0 = row_frag(qt, qfi * 16, 0, l15, lg), a1 = row_frag(qt, qfi * 16, 1, l15, lg);
             const uint4 g0 = row_frag(gt, qfi * 16, 0, l15, lg), g1 = row_frag(gt, qfi * 16, 1, l15, lg);
-            const f32x4 l4 = *reinterpret_cast<const f32x4*>(st + qfi * 16 + 4 * lg);
+            f32x4 nl4 = *reinterpret_cast<const f32x4*>(st + qfi * 16 + 4 * lg);   // -lse (log2 units) of the 4 queries
             f32x4 nd4 = -*reinterpret_cast<const f32x4*>(st + 64 + qfi * 16 + 4 * lg);
             asm volatile("" : "+v"(nd4));   // one register quad, read as the C operand of both key fragments' chains
+            asm volatile("" : "+v"(nl4));
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-              f32x4 z = {0.f, 0.f, 0.f, 0.f};
+              f32x4 z = UNIT ? nl4 : (f32x4){0.f, 0.f, 0.f, 0.f};
               z = mfma16(a0, kf_[f][0], z);
-              z = mfma16(a1, kf_[f][1], z);  // S[q][key]
+              z = mfma16(a1, kf_[f][1], z);  // S[q][key] (UNIT: already minus lse, in log2 units)
               f32x4 w = mfma16(g0, vf_[f][0], nd4);   // row constants -delta as the initial accumulator
               w = mfma16(g1, vf_[f][1], w);           // dP[q][key] - delta[q]
               f32x4 p, dsv;
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                float pr = fast_exp2(z[r] * c2 - l4[r]);
+                float pr = UNIT ? fast_exp2(z[r]) : fast_exp2(z[r] * c2 + nl4[r]);
                 if (MASKED && qfi * 16 + lg * 4 + r >= nvalid) pr = 0.f;
                 p[r] = pr;
                 dsv[r] = pr * w[r];
@@ -823,15 +857,24 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
     __syncthreads();
     cur = cur == 2 ? 0 : cur + 1;
   };
-  for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{});
-  if (Tq % TKV)
-    tile_body(nt - 1, std::true_type{});
+#define NVIT_RUN_TILES(UNIT_)                                                          \
+  {                                                                                    \
+    for (int t = 0; t + 1 < nt; ++t) tile_body(t, std::false_type{}, UNIT_{});         \
+    if (Tq % TKV)                                                                      \
+      tile_body(nt - 1, std::true_type{}, UNIT_{});                                    \
+    else                                                                               \
+      tile_body(nt - 1, std::false_type{}, UNIT_{});                                   \
+  }
+  if (unit)
+    NVIT_RUN_TILES(std::true_type)
   else
-    tile_body(nt - 1, std::false_type{});
+    NVIT_RUN_TILES(std::false_type)
+#undef NVIT_RUN_TILES
+  const float dks = scale / qpre;   // d/d(k_hat) = scale * dS^T q_hat, and the Q tiles hold qpre * q_hat
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int f = 0; f < 2; ++f) dk[i][f] = dk[i][f] * scale;
+    for (int f = 0; f < 2; ++f) dk[i][f] = dk[i][f] * dks;
   char* scr = &lds[0] + wid * 4096;   // (the tile loop ended with a barrier: the ring is free)
   if constexpr (FUSE) {
     if (wave_active)
@@ -849,12 +892,13 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
 
 }  // namespace
 
-int nvit_attn_fwd_mfma(const void* qh, const void* kh, const void* vh, float scale, const float* sqk, float c_q, void* o,
-                       float* lse, int B, int H, int Tq, int Tk, int d, hipStream_t s) {
+int nvit_attn_fwd_mfma(const void* qh, const void* kh, const void* vh, float scale, float qpre, const float* sqk,
+                       float c_q, void* o, float* lse, int B, int H, int Tq, int Tk, int d, hipStream_t s) {
   NVIT_REQUIRE(d == 64, "attn_fwd: the MFMA kernel supports head dim 64 only (got %d)", d);
+  NVIT_REQUIRE(qpre > 0.f, "attn_fwd: the q pre-scale must be positive (got %g)", (double)qpre);
   dim3 grid((unsigned)(cdiv(Tq, 128) * B * H));
   hipLaunchKernelGGL(attn_fwd_mfma_kernel, grid, dim3(256), 0, s, (const bf16*)qh, (const bf16*)kh, (const bf16*)vh,
-                     scale, sqk, c_q, (bf16*)o, lse, H, Tq, Tk);
+                     scale, qpre, sqk, c_q, (bf16*)o, lse, H, Tq, Tk);
   NVIT_CHECK_LAUNCH("attn_fwd_mfma");
   return NVIT_OK;
 }
@@ -866,11 +910,13 @@ int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const v
   NVIT_REQUIRE(o != nullptr && delta != nullptr, "attn_bwd: the attention output and the [2,B,H,Tq] side buffer are required");
   dim3 gq((unsigned)(cdiv(Tq, 128) * B * H)), gk((unsigned)(cdiv(Tk, 128) * B * H));
   QkFuse none{};
+  none.xs = 1.0f;
   hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<false>, gq, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
-                     (const bf16*)kh, (const bf16*)vh, lse, (const bf16*)o, delta, scale, (bf16*)dqh, H, Tq, Tk, none);
+                     (const bf16*)kh, (const bf16*)vh, lse, (const bf16*)o, delta, scale, 1.0f, (bf16*)dqh, H, Tq, Tk,
+                     none);
   NVIT_CHECK_LAUNCH("attn_bwd_dq_mfma");
   hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<false>, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
-                     (const bf16*)kh, (const bf16*)vh, lse, delta, scale, (bf16*)dkh, (bf16*)dvh, H, Tq, Tk, none);
+                     (const bf16*)kh, (const bf16*)vh, lse, delta, scale, 1.0f, (bf16*)dkh, (bf16*)dvh, H, Tq, Tk, none);
   NVIT_CHECK_LAUNCH("attn_bwd_dkv_mfma");
   return NVIT_OK;
 }
@@ -879,20 +925,22 @@ int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const v
 // (row stride ld) and the partial sums part_q [B*ceil(Tq/128), C], part_k [B*ceil(Tk/128), C].
 int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, const void* vh, const void* o,
                              const float* lse, float* delta, float scale, const float* rq, const float* rk, const float* sqk,
-                             float c_q, void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q, float* part_k, int B,
-                             int H, int Tq, int Tk, int d, hipStream_t s) {
+                             float c_q, float qpre, void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q,
+                             float* part_k, int B, int H, int Tq, int Tk, int d, hipStream_t s) {
   NVIT_REQUIRE(d == 64, "attn_bwd: the MFMA kernel supports head dim 64 only (got %d)", d);
   NVIT_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0, "attn_bwd: leading dims must be multiples of 4");
   NVIT_REQUIRE(o != nullptr && delta != nullptr, "attn_bwd: the attention output and the [2,B,H,Tq] side buffer are required");
   dim3 gq((unsigned)(cdiv(Tq, 128) * B * H)), gk((unsigned)(cdiv(Tk, 128) * B * H));
-  QkFuse fq{rq, sqk, c_q, (bf16*)dq, nullptr, ldq, part_q};
-  QkFuse fk{rk, sqk, c_q, (bf16*)dk, (bf16*)dv, ldkv, part_k};
+  NVIT_REQUIRE(qpre > 0.f, "attn_bwd: the q pre-scale must be positive (got %g)", (double)qpre);
+  QkFuse fq{rq, sqk, c_q, (bf16*)dq, nullptr, ldq, part_q, 1.0f / qpre};
+  QkFuse fk{rk, sqk, c_q, (bf16*)dk, (bf16*)dv, ldkv, part_k, 1.0f};
   hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, gq, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
-                     (const bf16*)kh, (const bf16*)vh, lse, (const bf16*)o, delta, scale, (bf16*)nullptr, H, Tq, Tk, fq);
+                     (const bf16*)kh, (const bf16*)vh, lse, (const bf16*)o, delta, scale, qpre, (bf16*)nullptr, H, Tq, Tk,
+                     fq);
   NVIT_CHECK_LAUNCH("attn_bwd_dq_mfma_fused");
   hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
-                     (const bf16*)kh, (const bf16*)vh, lse, delta, scale, (bf16*)nullptr, (bf16*)nullptr, H, Tq, Tk,
-                     fk);
+                     (const bf16*)kh, (const bf16*)vh, lse, delta, scale, qpre, (bf16*)nullptr, (bf16*)nullptr, H, Tq,
+                     Tk, fk);
   NVIT_CHECK_LAUNCH("attn_bwd_dkv_mfma_fused");
   return NVIT_OK;
 }

@@ -191,44 +191,48 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_ref(const T* dout, const T* q
 
 }  // namespace
 
-int nvit_attn_fwd_mfma(const void* qh, const void* kh, const void* vh, float scale, const float* sqk, float c_q, void* o,
-                       float* lse, int B, int H, int Tq, int Tk, int d, hipStream_t s);
+int nvit_attn_fwd_mfma(const void* qh, const void* kh, const void* vh, float scale, float qpre, const float* sqk,
+                       float c_q, void* o, float* lse, int B, int H, int Tq, int Tk, int d, hipStream_t s);
 int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const void* vh, const void* o, const float* lse,
                        float* delta, float scale, void* dqh, void* dkh, void* dvh, int B, int H, int Tq, int Tk,
                        int d, hipStream_t s);
 
 int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, const void* vh, const void* o,
                              const float* lse, float* delta, float scale, const float* rq, const float* rk, const float* sqk,
-                             float c_q, void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q, float* part_k, int B,
-                             int H, int Tq, int Tk, int d, hipStream_t s);
+                             float c_q, float qpre, void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q,
+                             float* part_k, int B, int H, int Tq, int Tk, int d, hipStream_t s);
 
 static int attn_fwd_impl(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, const float* sqk,
-                         float c_q, void* o, float* lse, int B, int H, int Tq, int Tk, int d, void* stream);
+                         float c_q, float qpre, void* o, float* lse, int B, int H, int Tq, int Tk, int d, void* stream);
 
 extern "C" int nvit_attn_fwd(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, void* o,
                              float* lse, int B, int H, int Tq, int Tk, int d, void* stream) {
-  return attn_fwd_impl(dt, impl, qh, kh, vh, scale, nullptr, 0.f, o, lse, B, H, Tq, Tk, d, stream);
+  return attn_fwd_impl(dt, impl, qh, kh, vh, scale, nullptr, 0.f, 1.0f, o, lse, B, H, Tq, Tk, d, stream);
 }
 
 // nViT call sites: q and k are (sqk*c_q) * unit vectors per head, which bounds every score; the MFMA kernel then skips
-// the running maximum (see attn_mfma.hip).  Same result as nvit_attn_fwd up to rounding.
+// the running maximum (see attn_mfma.hip).  Same result as nvit_attn_fwd up to rounding.  q_prescale: qh holds
+// q_prescale * q_hat (the producer folded the factor into the learned scale); 1 = plain.  With q_prescale =
+// scale * log2(e) the MFMA kernel's exponent needs no multiply (the fused training path).
 extern "C" int nvit_attn_fwd_bounded(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale,
-                                     const float* sqk, float c_q, void* o, float* lse, int B, int H, int Tq, int Tk, int d,
-                                     void* stream) {
+                                     const float* sqk, float c_q, float q_prescale, void* o, float* lse, int B, int H,
+                                     int Tq, int Tk, int d, void* stream) {
   NVIT_REQUIRE(sqk != nullptr, "attn_fwd_bounded: sqk is NULL (use nvit_attn_fwd)");
-  return attn_fwd_impl(dt, impl, qh, kh, vh, scale, sqk, c_q, o, lse, B, H, Tq, Tk, d, stream);
+  NVIT_REQUIRE(q_prescale > 0.f, "attn_fwd_bounded: q_prescale must be positive");
+  return attn_fwd_impl(dt, impl, qh, kh, vh, scale, sqk, c_q, q_prescale, o, lse, B, H, Tq, Tk, d, stream);
 }
 
 static int attn_fwd_impl(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, const float* sqk,
-                         float c_q, void* o, float* lse, int B, int H, int Tq, int Tk, int d, void* stream) {
+                         float c_q, float qpre, void* o, float* lse, int B, int H, int Tq, int Tk, int d, void* stream) {
   NVIT_REQUIRE(d == 32 || d == 64, "attn_fwd: head dim %d unsupported (32 or 64)", d);
   NVIT_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "attn_fwd: empty problem");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(NVIT_KID_ATTN_FWD, 4.0 * B * H * (double)Tq * Tk * d, 0.0, s);
   if (impl == 1) {
     NVIT_REQUIRE(dt == NVIT_BF16, "attn_fwd: MFMA kernel needs bf16");
-    return nvit_attn_fwd_mfma(qh, kh, vh, scale, sqk, c_q, o, lse, B, H, Tq, Tk, d, s);
+    return nvit_attn_fwd_mfma(qh, kh, vh, scale, qpre, sqk, c_q, o, lse, B, H, Tq, Tk, d, s);
   }
+  scale = scale / qpre;   // the scalar kernels take the multiplier of q.k directly
   dim3 grid(cdiv(Tq, 64), B * H);
 #define L(T, D) \
   hipLaunchKernelGGL((attn_fwd_ref<T, D>), grid, dim3(64), 0, s, (const T*)qh, (const T*)kh, (const T*)vh, scale, (T*)o, lse, H, Tq, Tk)
@@ -277,12 +281,13 @@ extern "C" int nvit_attn_bwd(int dt, int impl, const void* dout, const void* qh,
 // MFMA attention backward (bf16, d = 64) with the q/k-normalise backward fused into the epilogues.
 extern "C" int nvit_attn_bwd_qknorm(int dt, const void* dout, const void* qh, const void* kh, const void* vh,
                                     const void* o, const float* lse, float scale, const float* rq, const float* rk,
-                                    const float* sqk, float c_q, void* dq, int ldq, void* dk, void* dv, int ldkv, float* part_q,
-                                    float* part_k, float* delta, int B, int H, int Tq, int Tk, int d, void* stream) {
+                                    const float* sqk, float c_q, float q_prescale, void* dq, int ldq, void* dk, void* dv,
+                                    int ldkv, float* part_q, float* part_k, float* delta, int B, int H, int Tq, int Tk,
+                                    int d, void* stream) {
   NVIT_REQUIRE(dt == NVIT_BF16 && d == 64, "attn_bwd_qknorm: needs bf16 and head dim 64");
   NVIT_REQUIRE(B > 0 && H > 0 && Tq > 0 && Tk > 0, "attn_bwd_qknorm: empty problem");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(NVIT_KID_ATTN_BWD, 10.0 * B * H * (double)Tq * Tk * d, 0.0, s);
-  return nvit_attn_bwd_mfma_fused(dout, qh, kh, vh, o, lse, delta, scale, rq, rk, sqk, c_q, dq, ldq, dk, dv, ldkv, part_q,
-                                  part_k, B, H, Tq, Tk, d, s);
+  return nvit_attn_bwd_mfma_fused(dout, qh, kh, vh, o, lse, delta, scale, rq, rk, sqk, c_q, q_prescale, dq, ldq, dk, dv,
+                                  ldkv, part_q, part_k, B, H, Tq, Tk, d, s);
 }

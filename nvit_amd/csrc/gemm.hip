@@ -565,14 +565,15 @@ extern "C" int nvit_gemm_nt_swiglu_bwd(int dt, const void* A, int lda, const voi
 }
 
 extern "C" int nvit_gemm_nt_qknorm(int dt, const void* A, int lda, const void* B, int ldb, int M, int K, int nparts,
-                                   int part0, const float* sqk, float c_q, void* qh, void* kh, void* vh, float* rq,
-                                   float* rk, int T, int H, int d, void* stream) {
+                                   int part0, const float* sqk, float c_q, float q_prescale, void* qh, void* kh, void* vh,
+                                   float* rq, float* rk, int T, int H, int d, void* stream) {
   const int C = H * d;
   NVIT_REQUIRE(d == 64 && C % 256 == 0 && nparts >= 1 && part0 >= 0 && part0 + nparts <= 3,
                "gemm_nt_qknorm: needs head dim 64 and n_embd %% 256 == 0");
   NVIT_REQUIRE(nvit_gemm_nt_fusable(dt, M, nparts * C, K), "gemm_nt_qknorm: shape/dtype not eligible");
   NVIT_REQUIRE((lda * 2) % 16 == 0 && (ldb * 2) % 16 == 0 && lda >= K && ldb >= K, "gemm_nt_qknorm: bad leading dims");
   NVIT_REQUIRE(M % T == 0, "gemm_nt_qknorm: M must be a multiple of T");
+  NVIT_REQUIRE(q_prescale > 0.f, "gemm_nt_qknorm: q_prescale must be positive");
   NVIT_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)qh | (uintptr_t)kh | (uintptr_t)vh | (uintptr_t)sqk) & 15) == 0,
                "gemm_nt_qknorm: pointers must be 16-byte aligned");
   NtArgs g{};
@@ -584,6 +585,7 @@ extern "C" int nvit_gemm_nt_qknorm(int dt, const void* A, int lda, const void* B
   g.lda = lda;
   g.ldb = ldb;
   g.out_dt = NVIT_BF16;
+  g.q_prescale = q_prescale;
   g.qh = qh;
   g.kh = kh;
   g.vh = vh;

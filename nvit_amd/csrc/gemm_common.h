@@ -27,6 +27,7 @@ struct NtArgs {
   float *rq, *rk;      // [M,H] 1/||.||
   const float* sqk;
   float c_q;
+  float q_prescale;   // extra factor folded into the q part's scale (attention exponent pre-scale), 1 = none
   int part0, Cemb, Ttok, H;
   // --- fused SwiGLU-backward epilogue (EPI 5): acc = dx [M,Fh]; C = duv (interleaved, ldc = 2*Fh)
   const void* uv_in;  // raw pre-activations saved by EPI 3 (interleaved u16|v16 columns), bf16
@@ -274,8 +275,9 @@ __device__ __forceinline__ void nt_store_tile_qknorm(const NtArgs& g, f32x4 (&ac
   const int part = g.part0 + n_base / g.Cemb;  // 0 = q, 1 = k, 2 = v
   const int c0 = n_base % g.Cemb, h = c0 >> 6;
   f32x4 sc[4];
+  const float cq = part == 0 ? g.c_q * g.q_prescale : g.c_q;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) sc[j] = *reinterpret_cast<const f32x4*>(g.sqk + c0 + j * 16 + 4 * lg) * g.c_q;
+  for (int j = 0; j < 4; ++j) sc[j] = *reinterpret_cast<const f32x4*>(g.sqk + c0 + j * 16 + 4 * lg) * cq;
   bf16* outp = reinterpret_cast<bf16*>(part == 0 ? g.qh : (part == 1 ? g.kh : g.vh));
   float* rn_out = part == 0 ? g.rq : g.rk;
 #pragma unroll

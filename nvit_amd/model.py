@@ -259,9 +259,13 @@ class _BlockFn(torch.autograd.Function):
         has_b = bq is not None
         if not has_b and d == 64 and ops.fusable(dt, M, 3 * C, C):
             # q/k/v projection with the per-head normalise + sqk scale + head split in the GEMM epilogue
-            qh, kh, vh, rq, rk = ops.gemm_nt_qknorm(x_lo, sh[pre + "qkv.W"], M, C, 3, 0, sqk, c_q, B, T, H, d)
-            o, lse = ops.attn_fwd(dt, impl, qh, kh, vh, math.sqrt(d), sqk, c_q)
+            # (q leaves the epilogue pre-scaled by sqrt(d)*log2(e): the attention kernels' exponent needs no multiply)
+            qpre = ops.attn_q_prescale(d) if impl == 1 else 1.0
+            qh, kh, vh, rq, rk = ops.gemm_nt_qknorm(x_lo, sh[pre + "qkv.W"], M, C, 3, 0, sqk, c_q, B, T, H, d,
+                                                    q_prescale=qpre)
+            o, lse = ops.attn_fwd(dt, impl, qh, kh, vh, math.sqrt(d), sqk, c_q, q_prescale=qpre)
         else:
+            qpre = 1.0
             # small problems (128x128 GEMM kernel): the projections leave the GEMM in fp32 and are normalised from the
             # unrounded values, like the fused epilogue of the big-problem path (one rounding, at the head tensors)
             qkv = ops.gemm_nt(x_lo, sh[pre + "qkv.W"], M, 3 * C, C, out_dtype=torch.float32, bias=sh.get(pre + "qkv.b"))
@@ -292,6 +296,7 @@ class _BlockFn(torch.autograd.Function):
         if dt == F32:
             xn_lo = xn.new_empty(0)  # placeholder: callers alias x itself in fp32 mode (see _lo())
         ctx.rt, ctx.idx, ctx.with_skip, ctx.impl, ctx.has_b = rt, idx, with_skip, impl, has_b
+        ctx.qpre = qpre
         ctx.dims = (B, T, C, H, d, M)
         ctx.par = (skip_param, attn_alpha, mlp_alpha, sqk, suv, wq, wk, wv, wo, wfc, wp)   # gradient destinations
         ctx.save_for_backward(x, x_lo, qh, kh, vh, rq, rk, o, lse, y, h1, h1_lo, uv, xm, y2, skip_param, attn_alpha,
@@ -357,7 +362,7 @@ class _BlockFn(torch.autograd.Function):
         if impl == 1 and d == 64 and dt != F32:
             # attention backward with the q/k-normalise backward fused into its epilogues
             part_q, part_k = ops.attn_bwd_qknorm(do, qh, kh, vh, o, lse, math.sqrt(d), rq, rk, sqk, c_q, dqkv, 3 * C,
-                                                 dqkv[:, C:], dqkv[:, 2 * C:], 3 * C)
+                                                 dqkv[:, C:], dqkv[:, 2 * C:], 3 * C, q_prescale=ctx.qpre)
             d_sqk = _param_grad_scaled(rt, part_q, p_sqk, c_q)
             ops.colsum_reduce(part_k, d_sqk, True, kind=0, scale=c_q)
         else:
@@ -401,10 +406,12 @@ class _CrossFn(torch.autograd.Function):
             glo_lo = ops.cast(glo, dt) if glo_lo is None else glo_lo
         if not has_b and d == 64 and ops.fusable(dt, M, C, C):
             bufs = ops.qk_buffers(dt, B, T, H, d, loc.device)
-            ops.gemm_nt_qknorm(loc_lo, sh["x.q.W"], M, C, 1, 0, sqk, c_q, B, T, H, d, bufs)
+            qpre = ops.attn_q_prescale(d) if impl == 1 else 1.0
+            ops.gemm_nt_qknorm(loc_lo, sh["x.q.W"], M, C, 1, 0, sqk, c_q, B, T, H, d, bufs, q_prescale=qpre)
             qh, kh, vh, rq, rk = ops.gemm_nt_qknorm(glo_lo, sh["x.kv.W"], M, C, 2, 1, sqk, c_q, B, T, H, d, bufs)
-            o, lse = ops.attn_fwd(dt, impl, qh, kh, vh, math.sqrt(d), sqk, c_q)
+            o, lse = ops.attn_fwd(dt, impl, qh, kh, vh, math.sqrt(d), sqk, c_q, q_prescale=qpre)
         else:
+            qpre = 1.0
             q = ops.gemm_nt(loc_lo, sh["x.q.W"], M, C, C, out_dtype=torch.float32, bias=sh.get("x.q.b"))
             kv = ops.gemm_nt(glo_lo, sh["x.kv.W"], M, 2 * C, C, out_dtype=torch.float32, bias=sh.get("x.kv.b"))
             qh, kh, vh, rq, rk, o, lse = _attn_part_fwd(rt, impl, q, C, kv, 2 * C, kv[:, C:], 2 * C, sqk, c_q, B, T,
@@ -425,6 +432,7 @@ class _CrossFn(torch.autograd.Function):
         if dt == F32:
             x_lo = x.new_empty(0)
         ctx.rt, ctx.impl, ctx.has_b = rt, impl, has_b
+        ctx.qpre = qpre
         ctx.dims = (B, T, C, H, d, M)
         ctx.par = (attn_alpha, sqk, wq, wk, wv, wproj, wout)
         ctx.save_for_backward(loc, glo, loc_lo, glo_lo, qh, kh, vh, rq, rk, o, lse, pr, g, y, attn_alpha, sqk)
@@ -462,7 +470,7 @@ class _CrossFn(torch.autograd.Function):
         dkv = torch.empty((M, 2 * C), device=dev, dtype=td)
         if impl == 1 and d == 64 and dt != F32:
             part_q, part_k = ops.attn_bwd_qknorm(do, qh, kh, vh, o, lse, math.sqrt(d), rq, rk, sqk, c_q, dq, C, dkv,
-                                                 dkv[:, C:], 2 * C)
+                                                 dkv[:, C:], 2 * C, q_prescale=ctx.qpre)
             d_sqk = _param_grad_scaled(rt, part_q, p_sqk, c_q)
             ops.colsum_reduce(part_k, d_sqk, True, kind=0, scale=c_q)
         else:

@@ -109,16 +109,26 @@ def qk_buffers(dt: int, B: int, T: int, H: int, d: int, device):
             torch.empty((B * T, H), device=device, dtype=torch.float32))
 
 
+LOG2E = 1.4426950408889634
+
+
+def attn_q_prescale(d: int) -> float:
+    """The factor that, folded into q_hat by its producer, turns the MFMA result into the score in log2 units:
+    sqrt(d) * log2(e) - the exponent of the attention kernels then needs no multiply (nvit_attn_fwd_bounded)."""
+    return math.sqrt(d) * LOG2E
+
+
 def gemm_nt_qknorm(A: Tensor, B: Tensor, M: int, K: int, nparts: int, part0: int, sqk: Tensor, c_q: float, Bsz: int,
-                   T: int, H: int, d: int, bufs=None):
-    """q/k/v projection(s) with the per-head normalise, sqk scale and head split fused (bf16, d=64)."""
+                   T: int, H: int, d: int, bufs=None, q_prescale: float = 1.0):
+    """q/k/v projection(s) with the per-head normalise, sqk scale and head split fused (bf16, d=64).
+    q_prescale: extra factor folded into the q part (pass the same value to attn_fwd / attn_bwd_qknorm)."""
     _chk_dev(A, B)
     if bufs is None:
         bufs = qk_buffers(dt_of(A), Bsz, T, H, d, A.device)
     qh, kh, vh, rq, rk = bufs
     check(_lib.load().nvit_gemm_nt_qknorm(dt_of(A), _p(A), A.stride(0), _p(B), B.stride(0), M, K, nparts, part0,
-                                          _p(sqk), c_q, _p(qh), _p(kh), _p(vh), _p(rq), _p(rk), T, H, d, _s()),
-          "nvit_gemm_nt_qknorm")
+                                          _p(sqk), c_q, q_prescale, _p(qh), _p(kh), _p(vh), _p(rq), _p(rk), T, H, d,
+                                          _s()), "nvit_gemm_nt_qknorm")
     return bufs
 
 
@@ -330,16 +340,18 @@ def scale_cols(a: Tensor, s: Tensor, c: float, R: int, N: int, out: Tensor, lda:
 
 # ----------------------------------------------------------------------------- attention
 def attn_fwd(dt: int, impl: int, qh: Tensor, kh: Tensor, vh: Tensor, scale: float, sqk: Optional[Tensor] = None,
-             c_q: float = 0.0):
-    """sqk/c_q given: q and k are (sqk*c_q) * unit vectors per head (the nViT call sites) -> bounded-score kernel path."""
+             c_q: float = 0.0, q_prescale: float = 1.0):
+    """sqk/c_q given: q and k are (sqk*c_q) * unit vectors per head (the nViT call sites) -> bounded-score kernel path;
+    q_prescale: qh holds q_prescale * q_hat (only with sqk)."""
     B, H, Tq, d = qh.shape
     Tk = kh.shape[2]
     o = torch.empty((B * Tq, H * d), device=qh.device, dtype=tdtype(dt))
     lse = torch.empty((B, H, Tq), device=qh.device, dtype=torch.float32)
     if sqk is not None:
-        check(_lib.load().nvit_attn_fwd_bounded(dt, impl, _p(qh), _p(kh), _p(vh), scale, _p(sqk), c_q, _p(o), _p(lse), B,
-                                                H, Tq, Tk, d, _s()), "nvit_attn_fwd_bounded")
+        check(_lib.load().nvit_attn_fwd_bounded(dt, impl, _p(qh), _p(kh), _p(vh), scale, _p(sqk), c_q, q_prescale, _p(o),
+                                                _p(lse), B, H, Tq, Tk, d, _s()), "nvit_attn_fwd_bounded")
     else:
+        assert q_prescale == 1.0
         check(_lib.load().nvit_attn_fwd(dt, impl, _p(qh), _p(kh), _p(vh), scale, _p(o), _p(lse), B, H, Tq, Tk, d, _s()),
               "nvit_attn_fwd")
     return o, lse
@@ -360,7 +372,7 @@ def attn_bwd(dt: int, impl: int, dout: Tensor, qh: Tensor, kh: Tensor, vh: Tenso
 
 def attn_bwd_qknorm(dout: Tensor, qh: Tensor, kh: Tensor, vh: Tensor, o: Tensor, lse: Tensor, scale: float,
                     rq: Tensor, rk: Tensor, sqk: Tensor, c_q: float, dq: Tensor, ldq: int, dk: Tensor, dv: Tensor,
-                    ldkv: int):
+                    ldkv: int, q_prescale: float = 1.0):
     """MFMA attention backward + q/k-normalise backward in one pass (bf16, d=64).
     Writes dq/dk/dv token-major; returns the partial sums (part_q, part_k) of d/d(sqk*c_q)."""
     B, H, Tq, d = qh.shape
@@ -368,9 +380,9 @@ def attn_bwd_qknorm(dout: Tensor, qh: Tensor, kh: Tensor, vh: Tensor, o: Tensor,
     dev = qh.device
     part_q = torch.empty((B * math.ceil(Tq / 128), H * d), device=dev, dtype=torch.float32)
     part_k = torch.empty((B * math.ceil(Tk / 128), H * d), device=dev, dtype=torch.float32)
-    delta = torch.empty((2, B, H, Tq), device=dev, dtype=torch.float32)   # delta | lse*log2(e)
+    delta = torch.empty((2, B, H, Tq), device=dev, dtype=torch.float32)   # delta | -lse*log2(e)
     check(_lib.load().nvit_attn_bwd_qknorm(BF16, _p(dout), _p(qh), _p(kh), _p(vh), _p(o), _p(lse), scale, _p(rq),
-                                           _p(rk), _p(sqk), c_q, _p(dq), ldq, _p(dk), _p(dv), ldkv, _p(part_q),
+                                           _p(rk), _p(sqk), c_q, q_prescale, _p(dq), ldq, _p(dk), _p(dv), ldkv, _p(part_q),
                                            _p(part_k), _p(delta), B, H, Tq, Tk, d, _s()), "nvit_attn_bwd_qknorm")
     return part_q, part_k
 

@@ -610,3 +610,60 @@ def test_kohonen_map_update_periodic_and_plain(periodic):
     got = km.get_neighborhood_distances(bmu.to(d)).cpu()
     assert torch.equal(got, O.som_neighborhood_d2(bmu, km.m, km.n, periodic))
     assert got[0].item() == (2.0 if periodic else 41.0)     # node (0,0): wrapped (1,1) away vs (4,5) away
+
+
+@pytest.mark.parametrize("B,T", [(110, 50), (8, 784), (44, 130)])
+def test_attention_q_prescale_path_matches_plain(B, T):
+    """The training path folds sqrt(d)*log2(e) into q at its producer (GEMM epilogue 4) so that the attention kernels'
+    exponent needs no multiply (accumulator seeded with -bound / -lse, straight into v_exp_f32).  Same inputs through
+    the plain path (q_prescale = 1) and the pre-scaled one: q_hat differs only by its bf16 rounding, outputs, lse and
+    every gradient (d qkv token-major, d sqk) must agree to bf16 rounding; and both against fp32 torch math."""
+    ops = ops_()
+    from nvit_amd._lib import BF16
+    d_ = dev()
+    H, d = 4, 64
+    C = H * d
+    M = B * T
+    if not ops.fusable(BF16, M, 3 * C, C):
+        pytest.skip("shape below the fused-epilogue threshold")
+    X = rnd(M, C, seed=4).bfloat16().to(d_)
+    Wqkv = (rnd(3 * C, C, seed=5) * 0.05).bfloat16().to(d_)
+    sqk = ((1.0 + 0.2 * torch.tanh(rnd(C, seed=6))) / 32).to(d_)
+    c_q, scale = 32.0, math.sqrt(d)
+    qpre = ops.attn_q_prescale(d)
+    g_tok = rnd(M, C, seed=8).bfloat16().to(d_)
+    res = {}
+    for tag, qp in (("plain", 1.0), ("pre", qpre)):
+        qh, kh, vh, rq, rk = ops.gemm_nt_qknorm(X, Wqkv, M, C, 3, 0, sqk, c_q, B, T, H, d, q_prescale=qp)
+        o, lse = ops.attn_fwd(BF16, 1, qh, kh, vh, scale, sqk, c_q, q_prescale=qp)
+        dqkv = torch.empty((M, 3 * C), device=d_, dtype=torch.bfloat16)
+        pq, pk = ops.attn_bwd_qknorm(g_tok, qh, kh, vh, o, lse, scale, rq, rk, sqk, c_q, dqkv, 3 * C, dqkv[:, C:],
+                                     dqkv[:, 2 * C:], 3 * C, q_prescale=qp)
+        dsq = torch.empty(C, device=d_)
+        ops.colsum_reduce(pq, dsq, False, kind=0, scale=c_q)
+        ops.colsum_reduce(pk, dsq, True, kind=0, scale=c_q)
+        res[tag] = (qh.float(), kh.float(), o.float(), lse, dqkv.float(), dsq)
+    qh0, kh0, o0, lse0, dqkv0, dsq0 = res["plain"]
+    qh1, kh1, o1, lse1, dqkv1, dsq1 = res["pre"]
+    assert (qh1 / qpre - qh0).abs().max().item() < 2.0 ** -7 * qh0.abs().max().item()      # two bf16 roundings (half an ulp each, different binades) apart
+    assert torch.equal(kh1, kh0)
+    assert (o1 - o0).abs().max().item() < 1e-2 + 2.0 ** -7 * o0.abs().max().item()
+    assert (lse1 - lse0).abs().max().item() < 1e-2      # (scores up to ~10 from two differently rounded q_hat: 2^-9 relative each)
+    assert (dqkv1 - dqkv0).abs().max().item() < 2e-2 * max(1e-3, dqkv0.abs().max().item())
+    assert (dsq1 - dsq0).abs().max().item() < 2e-2 * max(1e-3, dsq0.abs().max().item())
+    # fp32 torch math from the same bf16 operands (autograd through normalise -> scale -> attention)
+    Xf = X.float().requires_grad_(True)
+    sq = sqk.clone().requires_grad_(True)
+    acc = (Xf @ Wqkv.float().t()).reshape(B, T, 3, H, d).permute(2, 0, 3, 1, 4)
+    s_eff = (sq * c_q).reshape(1, H, 1, d)
+    q = acc[0] / acc[0].norm(dim=-1, keepdim=True) * s_eff
+    k = acc[1] / acc[1].norm(dim=-1, keepdim=True) * s_eff
+    oref, lref = _sdpa_ref(q, k, acc[2], scale)
+    o_tok = oref.permute(0, 2, 1, 3).reshape(M, C)
+    o_tok.backward(g_tok.float())
+    assert (o1 - o_tok.detach()).abs().max().item() < 2e-2 * max(1.0, o_tok.abs().max().item())
+    assert (lse1 - lref.detach()).abs().max().item() < 1e-2
+    assert (dsq1 - sq.grad).abs().max().item() < 3e-2 * max(1e-3, sq.grad.abs().max().item())
+    # d(qkv) feeds the data-gradient GEMM: compare through it, dX = dqkv @ Wqkv
+    dX = dqkv1 @ Wqkv.float()
+    assert (dX - Xf.grad).abs().max().item() < 3e-2 * max(1e-3, Xf.grad.abs().max().item())

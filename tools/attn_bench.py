@@ -21,6 +21,8 @@ rq = 1.0 + rn(M, H).abs() * 0.1
 rk = 1.0 + rn(M, H).abs() * 0.1
 scale = math.sqrt(d)
 o, lse = ops.attn_fwd(BF16, 1, q, k, v, scale, sqk, 32.0)
+qpre = ops.attn_q_prescale(d)
+qs = (q.float() * qpre).bfloat16()     # what GEMM epilogue 4 writes on the training path (q_prescale folded in)
 dqkv = torch.empty(M, 3 * C, device=dev, dtype=torch.bfloat16)
 
 def t_of(fn, n=5):
@@ -37,6 +39,9 @@ cases = {
     "bwd unfused": (lambda: ops.attn_bwd(BF16, 1, gt, q, k, v, o, lse, scale), 10.0),
     "bwd fused  ": (lambda: ops.attn_bwd_qknorm(gt, q, k, v, o, lse, scale, rq, rk, sqk, 32.0, dqkv, 3 * C, dqkv[:, C:],
                                                 dqkv[:, 2 * C:], 3 * C), 10.0),
+    "fwd bounded, q pre-scaled": (lambda: ops.attn_fwd(BF16, 1, qs, k, v, scale, sqk, 32.0, q_prescale=qpre), 4.0),
+    "bwd fused,   q pre-scaled": (lambda: ops.attn_bwd_qknorm(gt, qs, k, v, o, lse, scale, rq, rk, sqk, 32.0, dqkv, 3 * C,
+                                                              dqkv[:, C:], dqkv[:, 2 * C:], 3 * C, q_prescale=qpre), 10.0),
 }
 res = {n: [] for n in cases}
 for rnd_ in range(5):
@@ -45,4 +50,4 @@ for rnd_ in range(5):
 for n, (fn, mult) in cases.items():
     ts = sorted(res[n]); med = ts[len(ts) // 2]
     fl = mult * B * H * T * T * d
-    print(f"{n}: median {med * 1e3:7.1f} us  min {ts[0] * 1e3:7.1f} us  {fl / med / 1e9:7.1f} TF/s algorithmic")
+    print(f"{n:26s}: median {med * 1e3:7.1f} us  min {ts[0] * 1e3:7.1f} us  {fl / med / 1e9:7.1f} TF/s algorithmic")
