@@ -63,9 +63,10 @@ __global__ __launch_bounds__(256) void lerp_fwd_kernel(LerpFwdArgs a) {
     for (int e = 0; e < 4; ++e) lam.v[i][e] = fabsf(lam.v[i][e] * a.c_a);
   const float skip = a.skip_x ? a.skip[0] : 0.f;
   for (int m = blockIdx.x * ROW_WAVES + wid; m < a.M; m += gridDim.x * ROW_WAVES) {
-    RowVec<NV> x, y, r;
+    RowVec<NV> x, y, r, xs;
     row_load<NV, float>(x, a.h + (size_t)m * a.C, a.C, lane);
     row_load<NV, TY>(y, reinterpret_cast<const TY*>(a.y) + (size_t)m * a.C, a.C, lane);
+    if (a.skip_x) row_load<NV, float>(xs, a.skip_x + (size_t)m * a.C, a.C, lane);   // with the others: one round trip per row
     const float rsx = 1.0f / sqrtf(row_dot<NV>(x, x));
     const float rsy = 1.0f / sqrtf(row_dot<NV>(y, y));
 #pragma unroll
@@ -77,8 +78,6 @@ __global__ __launch_bounds__(256) void lerp_fwd_kernel(LerpFwdArgs a) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) r.v[i] = r.v[i] * rsr;
     if (a.skip_x) {
-      RowVec<NV> xs;
-      row_load<NV, float>(xs, a.skip_x + (size_t)m * a.C, a.C, lane);
 #pragma unroll
       for (int i = 0; i < NV; ++i) r.v[i] = r.v[i] * skip + xs.v[i];
       const float rst = 1.0f / sqrtf(row_dot<NV>(r, r));
@@ -124,10 +123,14 @@ __global__ __launch_bounds__(256) void lerp_bwd_kernel(LerpBwdArgs a) {
   const float skip = a.skip_x ? a.skip[0] : 0.f;
   float dskip_acc = 0.f;
   for (int m = blockIdx.x * ROW_WAVES + wid; m < a.M; m += gridDim.x * ROW_WAVES) {
-    RowVec<NV> x, y, av, bv, o, g;
+    RowVec<NV> x, y, av, bv, o, g, t, old;
     row_load<NV, float>(x, a.h + (size_t)m * a.C, a.C, lane);
     row_load<NV, TY>(y, reinterpret_cast<const TY*>(a.y) + (size_t)m * a.C, a.C, lane);
     row_load<NV, float>(g, a.dout + (size_t)m * a.C, a.C, lane);
+    // every load of the row goes out before the first reduction: one memory round trip per row, not two or three
+    float* const dhp = a.dh + (size_t)m * a.C;
+    if (a.skip_x) row_load<NV, float>(t, a.skip_x + (size_t)m * a.C, a.C, lane);
+    if (a.accum_dh) row_load<NV, float>(old, dhp, a.C, lane);
     const float rsx = 1.0f / sqrtf(row_dot<NV>(x, x));
     const float rsy = 1.0f / sqrtf(row_dot<NV>(y, y));
 #pragma unroll
@@ -141,8 +144,6 @@ __global__ __launch_bounds__(256) void lerp_bwd_kernel(LerpBwdArgs a) {
     for (int i = 0; i < NV; ++i) o.v[i] = o.v[i] * rsr;  // o = h2 = lerp output (unit norm)
     if (a.skip_x) {
       // t = o*skip + xs ; out = t/|t| ; dt = (g - out<out,g>)/|t| ; do = skip*dt ; dxs = dt ; dskip += <dt,o>
-      RowVec<NV> t;
-      row_load<NV, float>(t, a.skip_x + (size_t)m * a.C, a.C, lane);
 #pragma unroll
       for (int i = 0; i < NV; ++i) t.v[i] = o.v[i] * skip + t.v[i];
       const float rst = 1.0f / sqrtf(row_dot<NV>(t, t));
@@ -173,10 +174,7 @@ __global__ __launch_bounds__(256) void lerp_bwd_kernel(LerpBwdArgs a) {
       da.v[i] = (da.v[i] - av.v[i] * ada) * rsx;  // dh
       db.v[i] = (db.v[i] - bv.v[i] * bdb) * rsy;  // dy
     }
-    float* dhp = a.dh + (size_t)m * a.C;
     if (a.accum_dh) {
-      RowVec<NV> old;
-      row_load<NV, float>(old, dhp, a.C, lane);
 #pragma unroll
       for (int i = 0; i < NV; ++i) da.v[i] += old.v[i];
     }
