@@ -555,8 +555,13 @@ __global__ void normalize_images_kernel(const IN* in, float* out, int B, int C, 
 }
 
 int row_grid(int M) {
+  static int cap = 0;
+  if (cap == 0) {
+    const char* e = getenv("NVIT_ROW_GRID");   // experiments
+    cap = e ? atoi(e) : 2048;
+  }
   int blocks = cdiv(M, ROW_WAVES);
-  return blocks > 2048 ? 2048 : blocks;
+  return blocks > cap ? cap : blocks;
 }
 
 }  // namespace

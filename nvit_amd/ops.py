@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -184,7 +185,7 @@ def gemm_tn(A: Tensor, B: Tensor, G: Tensor, Mred: int, N: int, K: int, perm: in
 
 
 # ----------------------------------------------------------------------------- row ops
-PART_BLOCKS = 1024
+PART_BLOCKS = int(os.environ.get("NVIT_PART_BLOCKS", "1024"))   # workgroups of the backward row kernels (experiments: env)
 
 
 def lerp_fwd(dt: int, h: Tensor, y: Tensor, alpha: Tensor, c_a: float, skip_x: Optional[Tensor] = None,
