@@ -26,11 +26,11 @@ def _free_port():
     return p
 
 
-def _run(name, tmp_path, collective="rccl"):
+def _run(name, tmp_path, collective="rccl", world=2):
     port = _free_port()
     procs, outs = [], []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         out = tmp_path / f"{name}_{rank}.json"
         outs.append(out)
@@ -85,6 +85,22 @@ def test_dp_two_ranks_direct_xgmi_collective(tmp_path):
     """Same run with the hand-written reduce-scatter / all-gather instead of torch.distributed's
     all-reduce: all buckets in one IPC-mapped symmetric buffer, reduced once at the end of backward."""
     res = _run("mini", tmp_path, collective="xgmi")
+    for r in res:
+        for step in range(3):
+            assert r[f"ranks_equal_step{step}"] and r[f"aligned_step{step}"]
+        assert r["params_equal_across_ranks"]
+    r0 = res[0]
+    assert r0["grad_err_vs_single_process"][0] < 5e-6, r0
+    assert max(r0["grad_err_vs_single_process"]) < 3e-4 and r0["param_err_vs_single_process"] < 1e-4, r0
+    assert r0["accum_err_vs_single_process"] < 3e-4, r0
+
+
+@pytest.mark.parametrize("collective", ["rccl", "xgmi"])
+def test_dp_four_ranks_real_model(tmp_path, collective):
+    """Four ranks (two images each) on the one device: bucketed all-reduce or the direct reduce-scatter / all-gather
+    over the IPC-mapped symmetric buffer, against the single-process run on the concatenated batch."""
+    res = _run("mini", tmp_path, collective=collective, world=4)
+    assert len(res) == 4
     for r in res:
         for step in range(3):
             assert r[f"ranks_equal_step{step}"] and r[f"aligned_step{step}"]
