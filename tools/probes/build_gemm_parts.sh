@@ -9,3 +9,7 @@ for v in full:NVIT_PROBE_NONE nodma:NVIT_PROBE_NO_DMA nomfma:NVIT_PROBE_NO_MFMA 
   /opt/rocm/bin/hipcc $FLAGS -D${v#*:} -c tools/probes/gemm_parts.hip -o tools/probes/bin/gp_${v%%:*}.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 tools/probes/bin/gp_${v%%:*}.o tools/probes/bin/core.o -o tools/probes/bin/gemm_parts_${v%%:*}
 done
+for v in full:NVIT_PROBE_NONE nodma:NVIT_PROBE_NO_DMA nomfma:NVIT_PROBE_NO_MFMA; do
+  /opt/rocm/bin/hipcc $FLAGS -D${v#*:} -c tools/probes/gemm_tn_parts.hip -o tools/probes/bin/gtn_${v%%:*}.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 tools/probes/bin/gtn_${v%%:*}.o tools/probes/bin/core.o -o tools/probes/bin/gemm_tn_parts_${v%%:*}
+done
