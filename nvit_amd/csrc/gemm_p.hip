@@ -150,6 +150,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
 #ifdef NVIT_PROBE_NO_DMA
   int probe_issued = 0;   // tools/probes/gemm_parts.hip: only the first NSLOT stages are really fetched
 #endif
+#ifdef NVIT_PROBE_NO_B_DMA
+  int probe_b = 0;
+#endif
   auto issue_stage = [&]() {
     const unsigned bo = lds_base + wave_off + (unsigned)l_slot * SLOT_BYTES;
     const size_t ko = (size_t)l_k * ROWB;
@@ -159,6 +162,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
     {
 #pragma unroll
       for (int i = 0; i < Cfg::A_DMA; ++i) glds16(ap[i] + ko, bo + i * 8192);
+#ifdef NVIT_PROBE_NO_B_DMA   // (probe: the B operand is fetched only for the first stages - half the LDS-DMA writes)
+      if (probe_b++ < NSLOT)
+#endif
 #pragma unroll
       for (int i = 0; i < Cfg::B_DMA; ++i) glds16(bp[i] + ko, bo + A_BYTES + i * 8192);
     }
@@ -244,11 +250,15 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
     const int r = wr * WROWS + (i_) * 16 + l15;                                                           \
     fa[kk_][i_] = *reinterpret_cast<const uint4*>(la_ + r * ROWB + ((((kk_) * 4 + lg) ^ (r & 7)) << 4));  \
   }
+#ifdef NVIT_PROBE_NO_B_READ   // (probe: B fragments without LDS reads - a third of the fragment traffic)
+#define RB(kk_, j_) { fb[kk_][j_] = make_uint4(0x3c003c00u + (kk_), 0x3c003c00u + (j_), 0x3c003c00u + l15, 0x3c003c00u + lg); }
+#else
 #define RB(kk_, j_)                                                                                       \
   {                                                                                                       \
     const int r = wc * 64 + (j_) * 16 + l15;                                                              \
     fb[kk_][j_] = *reinterpret_cast<const uint4*>(lb_ + r * ROWB + ((((kk_) * 4 + lg) ^ (r & 7)) << 4));  \
   }
+#endif
       __builtin_amdgcn_sched_barrier(0);
       RB(0, 0) RB(0, 1) RB(0, 2) RB(0, 3) RA(0, 0) RA(0, 1) RA(0, 2)
       if constexpr (FM == 8) {
