@@ -151,7 +151,32 @@ __device__ __forceinline__ void nt_store_tile_staged(const NtArgs& g, f32x4 (&ac
   constexpr int JPP = CPP / 16;           // accumulator column blocks per pass: 4 / 2
   constexpr int PASSES = 4 / JPP;         // 1 / 2
   constexpr int EPC_O = 16 / EO;          // output elements per 16-byte chunk
+  constexpr int NP = FMR * PASSES;        // passes of the wave's sub-tile (16 rows x 128 B of output each)
+  constexpr int PD = EO == 4 ? 4 : 1;     // fp32 accumulate: passes whose old C values are in flight ahead of their use
   const int l15 = lane & 15, lg = lane >> 4;
+  // fp32 "+=" (the data-gradient GEMMs that accumulate into the residual-stream gradient): the old C values are read
+  // through a register queue PD passes ahead.  Loaded at their point of use, each of the 16 passes of a wave waited a
+  // full memory round trip: 22 us of epilogue per tile instead of 9 (tools/probes/gemm_parts.hip with accumulate on).
+  // (the main loop's fragment registers are dead here, so the queue is free)
+  uint4 oldq[PD][2];
+  auto old_ptr = [&](int pass, int t) -> const TO* {
+    const int i = pass / PASSES, p = pass % PASSES;
+    const int idx = lane + 64 * t;
+    const int row = idx >> 3, chunk = idx & 7;
+    int m = m_base + i * 16 + row, n = n_base + p * CPP + chunk * EPC_O;
+    m = m < g.M ? m : g.M - 1;
+    n = n < g.N ? n : 0;
+    return reinterpret_cast<const TO*>(g.C) + (size_t)m * g.ldc + n;
+  };
+  const bool prefetch = EO == 4 && g.accumulate;
+  if constexpr (EO == 4) {
+    if (prefetch) {
+#pragma unroll
+      for (int q = 0; q < PD; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) oldq[q][t] = ld16_nt(old_ptr(q, t));
+    }
+  }
 #pragma unroll
   for (int i = 0; i < FMR; ++i) {
     const int mfrag = m_base + i * 16 + l15;
@@ -159,6 +184,7 @@ __device__ __forceinline__ void nt_store_tile_staged(const NtArgs& g, f32x4 (&ac
         g.rowadd ? g.rowadd + (size_t)((mfrag < g.M ? mfrag : g.M - 1) % g.rowadd_period) * g.N : nullptr;
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
+      const int pass = i * PASSES + p;
       // fragment layout -> scratch[row = l15][cols 16*jj + 4*lg .. +3]
 #pragma unroll
       for (int jj = 0; jj < JPP; ++jj) {
@@ -183,12 +209,19 @@ __device__ __forceinline__ void nt_store_tile_staged(const NtArgs& g, f32x4 (&ac
         const uint4 raw = *reinterpret_cast<const uint4*>(scratch + row * 128 + ((chunk ^ (row & 7)) << 4));
         const int m = m_base + i * 16 + row;
         const int n = n_base + p * CPP + chunk * EPC_O;
+        uint4 oldv = make_uint4(0u, 0u, 0u, 0u);
+        if constexpr (EO == 4) {
+          if (prefetch) {
+            oldv = oldq[pass % PD][t];
+            if (pass + PD < NP) oldq[pass % PD][t] = ld16_nt(old_ptr(pass + PD, t));
+          }
+        }
         if (m < g.M && n < g.N) {
           TO* cp = reinterpret_cast<TO*>(g.C) + (size_t)m * g.ldc + n;
           if (g.accumulate) {
             if constexpr (EO == 4) {
               f32x4 v = __builtin_bit_cast(f32x4, raw);
-              v += __builtin_bit_cast(f32x4, ld16_nt(cp));
+              v += __builtin_bit_cast(f32x4, oldv);
               st16_nt(cp, __builtin_bit_cast(uint4, v));
             } else {
               const bf16x8 nv = __builtin_bit_cast(bf16x8, raw);
