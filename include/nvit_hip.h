@@ -177,6 +177,12 @@ int nvit_lerp_bwd(int dt, const float* dout, const float* h, const void* y, int 
                   void* dy_lo, float* dskip_x, float* part_dlam, float* part_dskip, int nblk, int M, int C,
                   void* stream);
 
+/* RMSNorm (model.py:170-182; not on the nViT path, provided so that the public module works):
+ * out = x * rsqrt(mean(x^2) + eps) * w, fp32 [M, C]; rstd [M] saved for the backward.
+ * nvit_rmsnorm_bwd: dx [M, C] and part_dw [nblk, C] (per-workgroup partial sums of d(w); reduce with nvit_colsum_reduce). */
+int nvit_rmsnorm_fwd(const float* x, const float* w, float eps, float* out, float* rstd, int M, int C, void* stream);
+int nvit_rmsnorm_bwd(const float* dout, const float* x, const float* w, const float* rstd, float* dx, float* part_dw,
+                     int nblk, int M, int C, void* stream);
 /* Block.norm_skip on its own (model.py:84-87): out = nrm(src*skip[0] + tgt), fp32 [M,C]; backward writes dsrc, dtgt
  * (tgt == NULL / dtgt == NULL: the target term is absent, i.e. justnorm(src*skip[0]), model.py:43-44,89-90)
  * and part_dskip [nblk]. (ViT.forward uses the copy fused into nvit_lerp_fwd/bwd.) */

@@ -69,6 +69,8 @@ SIGNATURES = {
     "nvit_gather_rows": [_vp, _vp, _vp, _i64, _i, _vp],
     "nvit_scatter_rows": [_vp, _vp, _vp, _i64, _i, _i, _vp],
     "nvit_onehot": [_vp, _vp, _i64, _i, _vp],
+    "nvit_rmsnorm_fwd": [_vp, _vp, _f, _vp, _vp, _i, _i, _vp],
+    "nvit_rmsnorm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "nvit_som_update": [_vp, _vp, _vp, _f, _f, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp],
     "nvit_cos_consistency_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i64, _i, _vp],
     "nvit_cos_consistency_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp],

@@ -554,6 +554,64 @@ __global__ void normalize_images_kernel(const IN* in, float* out, int B, int C, 
   }
 }
 
+// ------------------------------------------------------------------------------ RMSNorm (reference model.py:170-182)
+// y = x * rsqrt(mean(x^2) + eps) * w.  Dead on the nViT path (its Block never calls it); kept as a working public module.
+template <int NV>
+__global__ __launch_bounds__(256) void rmsnorm_fwd_kernel(const float* x, const float* w, float eps, float* out,
+                                                           float* rstd, int M, int C) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  RowVec<NV> wv;
+  row_load<NV, float>(wv, w, C, lane);
+  for (int m = blockIdx.x * ROW_WAVES + wid; m < M; m += gridDim.x * ROW_WAVES) {
+    RowVec<NV> a;
+    row_load<NV, float>(a, x + (size_t)m * C, C, lane);
+    const float rs = 1.0f / sqrtf(row_dot<NV>(a, a) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) a.v[i] = a.v[i] * rs * wv.v[i];
+    row_store<NV, float>(a, out + (size_t)m * C, C, lane);
+    if (lane == 0) rstd[m] = rs;
+  }
+}
+
+// dx = rstd * (g*w - xn * mean(g*w*xn)),  xn = x * rstd;  part_dw[block][c] = sum over the block's rows of g * xn
+template <int NV>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const float* dout, const float* x, const float* w,
+                                                           const float* rstd, float* dx, float* part_dw, int M, int C) {
+  __shared__ float red[ROW_WAVES][NV * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  RowVec<NV> wv, dw;
+  row_load<NV, float>(wv, w, C, lane);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) dw.v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int m = blockIdx.x * ROW_WAVES + wid; m < M; m += gridDim.x * ROW_WAVES) {
+    RowVec<NV> a, g;
+    row_load<NV, float>(a, x + (size_t)m * C, C, lane);
+    row_load<NV, float>(g, dout + (size_t)m * C, C, lane);
+    const float rs = rstd[m];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      a.v[i] = a.v[i] * rs;            // xn
+      dw.v[i] += g.v[i] * a.v[i];
+      g.v[i] = g.v[i] * wv.v[i];       // g*w
+    }
+    const float mean = row_dot<NV>(g, a) / (float)C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) g.v[i] = (g.v[i] - a.v[i] * mean) * rs;
+    row_store<NV, float>(g, dx + (size_t)m * C, C, lane);
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[wid][(i * 64 + lane) * 4 + e] = dw.v[i][e];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float s_ = 0.f;
+#pragma unroll
+    for (int wv_ = 0; wv_ < ROW_WAVES; ++wv_) s_ += red[wv_][c];
+    part_dw[(size_t)blockIdx.x * C + c] = s_;
+  }
+}
+
 int row_grid(int M) {
   static int cap = 0;
   if (cap == 0) {
@@ -641,6 +699,27 @@ extern "C" int nvit_norm_skip_bwd(const float* dout, const float* src, const flo
                        part_dskip, M, C);
   });
   NVIT_CHECK_LAUNCH("norm_skip_bwd");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_rmsnorm_fwd(const float* x, const float* w, float eps, float* out, float* rstd, int M, int C,
+                                void* stream) {
+  NVIT_REQUIRE(C % 4 == 0 && C <= 2048 && M > 0, "rmsnorm_fwd: C=%d must be a multiple of 4 and <= 2048", C);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = row_grid(M);
+  DISPATCH_NV(C, { hipLaunchKernelGGL((rmsnorm_fwd_kernel<NV>), dim3(grid), dim3(256), 0, s, x, w, eps, out, rstd, M, C); });
+  NVIT_CHECK_LAUNCH("rmsnorm_fwd");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_rmsnorm_bwd(const float* dout, const float* x, const float* w, const float* rstd, float* dx,
+                                float* part_dw, int nblk, int M, int C, void* stream) {
+  NVIT_REQUIRE(C % 4 == 0 && C <= 2048 && M > 0 && nblk > 0 && nblk <= 4096, "rmsnorm_bwd: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_NV(C, {
+    hipLaunchKernelGGL((rmsnorm_bwd_kernel<NV>), dim3(nblk), dim3(256), 0, s, dout, x, w, rstd, dx, part_dw, M, C);
+  });
+  NVIT_CHECK_LAUNCH("rmsnorm_bwd");
   return NVIT_OK;
 }
 

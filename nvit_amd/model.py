@@ -42,8 +42,24 @@ def _dt_from_precision(p: str) -> int:
     raise ValueError(f"precision must be 'fp32' or 'bf16', got {p!r}")
 
 
+class _RMSNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+        out, rstd = ops.rmsnorm_fwd(x2, w.detach().contiguous().float(), eps)
+        ctx.save_for_backward(x2, w, rstd)
+        return out.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w, rstd = ctx.saved_tensors
+        dx, dw = ops.rmsnorm_bwd(g.reshape(x2.shape).contiguous().float(), x2, w.detach().contiguous().float(), rstd)
+        return dx.reshape(g.shape), dw, None
+
+
 class RMSNorm(nn.Module):
-    """Parameter container only (reference model.py:172-184; dead in nViT mode, kept for state_dict parity)."""
+    """reference model.py:170-182: x * rsqrt(mean(x^2) + eps) * weight, as one row kernel each way.  Dead in nViT mode
+    (no Block calls it; its parameters exist for state_dict parity) but a working public module."""
 
     def __init__(self, embdim: int, eps: float = 1e-6) -> None:
         super().__init__()
@@ -51,7 +67,11 @@ class RMSNorm(nn.Module):
         self.eps = eps
 
     def forward(self, x: Tensor) -> Tensor:
-        raise RuntimeError("RMSNorm is only reachable on the reference's non-nViT path, which is out of scope")
+        if not x.is_cuda:
+            raise RuntimeError("RMSNorm runs only on the HIP device (no CPU fallback)")
+        if x.dtype != torch.float32:
+            raise RuntimeError("RMSNorm: fp32 input expected (the reference computes it in fp32)")
+        return _RMSNormFn.apply(x, self.weight, self.eps)
 
 
 # --------------------------------------------------------------------------------------------

@@ -218,6 +218,27 @@ def lerp_bwd(dt: int, dout: Tensor, h: Tensor, y: Tensor, alpha: Tensor, c_a: fl
     return dh, dy, dy_lo, dskip_x, part, pskip
 
 
+def rmsnorm_fwd(x: Tensor, w: Tensor, eps: float):
+    M, Cc = x.shape
+    out = torch.empty_like(x)
+    rstd = torch.empty((M,), device=x.device, dtype=torch.float32)
+    check(_lib.load().nvit_rmsnorm_fwd(_p(x), _p(w), eps, _p(out), _p(rstd), M, Cc, _s()), "nvit_rmsnorm_fwd")
+    return out, rstd
+
+
+def rmsnorm_bwd(dout: Tensor, x: Tensor, w: Tensor, rstd: Tensor):
+    """-> dx [M,C], dw [C]"""
+    M, Cc = x.shape
+    nblk = min(PART_BLOCKS, math.ceil(M / 4))
+    dx = torch.empty_like(x)
+    part = torch.empty((nblk, Cc), device=x.device, dtype=torch.float32)
+    check(_lib.load().nvit_rmsnorm_bwd(_p(dout), _p(x), _p(w), _p(rstd), _p(dx), _p(part), nblk, M, Cc, _s()),
+          "nvit_rmsnorm_bwd")
+    dw = torch.empty((Cc,), device=x.device, dtype=torch.float32)
+    colsum_reduce(part, dw, False)
+    return dx, dw
+
+
 def norm_skip_fwd(src: Tensor, tgt: Optional[Tensor], skip: Tensor) -> Tensor:
     """nrm(src*skip + tgt); tgt None = justnorm(src*skip)."""
     M, Cc = src.shape

@@ -667,3 +667,25 @@ def test_attention_q_prescale_path_matches_plain(B, T):
     # d(qkv) feeds the data-gradient GEMM: compare through it, dX = dqkv @ Wqkv
     dX = dqkv1 @ Wqkv.float()
     assert (dX - Xf.grad).abs().max().item() < 3e-2 * max(1e-3, Xf.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("C", [64, 192, 768, 1024])
+def test_rmsnorm_module_fwd_bwd(C):
+    """nvit_amd.model.RMSNorm (reference model.py:170-182) against the formula in fp64 torch math, values and gradients."""
+    from nvit_amd.model import RMSNorm
+    d = dev()
+    x = rnd(5, 37, C, seed=1).requires_grad_(True)
+    w = (1.0 + rnd(C, seed=2, scale=0.2))
+    g = rnd(5, 37, C, seed=3)
+    xd, wd = x.detach().double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = xd * torch.rsqrt((xd * xd).mean(dim=-1, keepdim=True) + 1e-6) * wd
+    ref.backward(g.double())
+    mod = RMSNorm(C).to(d)
+    with torch.no_grad():
+        mod.weight.copy_(w)
+    xg = x.detach().to(d).requires_grad_(True)
+    out = mod(xg)
+    out.backward(g.to(d))
+    assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 2e-6
+    assert (xg.grad.cpu().double() - xd.grad).abs().max().item() < 5e-6
+    assert (mod.weight.grad.cpu().double() - wd.grad).abs().max().item() < 2e-5 * max(1.0, wd.grad.abs().max().item())
