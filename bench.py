@@ -84,17 +84,18 @@ def cpu_baseline(cfg_name: str, sample_batch: int, threads: int):
 
 
 def pmc_traffic():
-    """(HBM-side bytes per gemm_nt launch, the profile file they come from) from the committed rocprofv3 PMC summary
-    of this same command (profiles/*_pmc.json, made by tools/summarize_profile.py; PMC counters cannot be read inside
-    the run, so the source file is named in the JSON line and goes stale only visibly)."""
+    """(HBM-side bytes per plain gemm_nt launch, per-family bytes per launch, the profile file they come from) from the
+    committed rocprofv3 PMC summary of this same command (profiles/*_pmc.json, made by tools/summarize_profile.py; PMC
+    counters cannot be read inside the run, so the source file is named in the JSON line and goes stale only visibly)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc.json")))
     if not files:
-        return None, None
+        return None, {}, None
     try:
-        return float(json.load(open(files[-1]))["traffic_bytes_per_launch"]), os.path.basename(files[-1])
+        js = json.load(open(files[-1]))
+        return float(js["traffic_bytes_per_launch"]), js.get("families", {}), os.path.basename(files[-1])
     except Exception:
-        return None, None
+        return None, {}, None
 
 
 def _gemm_nt_algorithmic_bytes(cfg, batch: int) -> float:
@@ -108,6 +109,35 @@ def _gemm_nt_algorithmic_bytes(cfg, batch: int) -> float:
         return 2.0 * M * K + 2.0 * C * K + M * C * out_bytes * (2 if acc else 1)
     launches = [one(C, 4, False), one(4 * C, 4, False), one(8 * C, 4, True), one(3 * C, 4, True), one(C, 2, False)]
     return sum(launches) / len(launches)
+
+
+def run_parity(model, cfg, args, X):
+    """Parity facts of the benchmarked mode that can be stated without the CPU oracle (which bench.py touches only in
+    its cpu_baseline leg): logits of the first 4 images in the benchmarked precision against the exact-f32 mode of the
+    same HIP model (that mode is held to 1e-5 of the CPU oracle at this size by tests/test_gpu_model.py), outside the
+    timed region."""
+    model.eval()
+    with torch.no_grad():
+        lo, _ = model(X[:4])
+        model.set_precision("fp32")
+        ref, _ = model(X[:4])
+        model.set_precision(args.precision)
+    model.train()
+    d = (lo - ref).abs()
+    lmax = ref.abs().max().item()
+    out = {"what": f"{args.precision} logits vs the exact-f32 mode of the same model, first 4 images of the batch",
+           "max_abs": float(f"{d.max().item():.3e}"), "rms": float(f"{d.double().pow(2).mean().sqrt().item():.3e}"),
+           "logit_max_abs": round(lmax, 3), "max_rel_to_logit_range": float(f"{d.max().item() / lmax:.3e}"),
+           "fp32_mode_vs_cpu_oracle": "<= 1e-5 (tests/test_gpu_model.py, Base B=6: 2.1e-6)"}
+    if args.precision == "bf16":
+        out["north_star_tolerance"] = 1e-3
+        out["meets_1e-3_vs_fp32"] = bool(d.max().item() < 1e-3)
+        out["documented_deviation"] = (
+            "beyond the small configs the bf16 rounding of the GEMM operands alone moves the ORACLE's logits by more than "
+            "1e-3 (Base 2.7e-3, Large 4.0e-3; the reference's own autocast path 7.2e-3 at Base, SURVEY 9.3); the tests hold "
+            "the HIP path to 1e-3 of the CPU oracle that rounds the same operands at the same points, and two such "
+            "evaluations that differ only in summation order already differ by 4.5e-4 (Base) / 7.1e-4 (Large): DESIGN.md 2")
+    return out
 
 
 def run_check(model, cfg, args, X, dev):
@@ -263,7 +293,13 @@ def main() -> None:
         print(f"[bench] device: {torch.cuda.get_device_name(dev)}, {cus} CUs, max clock {mhz:.0f} MHz -> dense bf16 MFMA "
               f"peak {peak:.1f} TFLOP/s (nominal {NOMINAL_PEAK_BF16_TFLOPS})", file=sys.stderr, flush=True)
 
-        def fam_of(key, label, executed_mult=1.0):
+        traffic, fam_traffic, traffic_src = pmc_traffic()
+
+        def fam_of(key, label, executed_mult=1.0, pmc_key=None):
+            """MFMA view (algorithmic FLOPs / HIP-event time vs the dense bf16 peak) and HBM view (algorithmic bytes
+            declared at the launch / the same time vs 8 TB/s) of one kernel family; `bound` names the roofline the
+            family sits closer to.  `traffic_over_algorithmic`: fabric-side bytes per launch from the committed PMC
+            passes over the algorithmic bytes (well above 1 = re-fetched operands)."""
             f = prof.get(key)
             if not f or f["ms"] <= 0 or f["launches"] == 0:
                 return None
@@ -273,6 +309,16 @@ def main() -> None:
                  "avg_launch_ms": round(f["ms"] / f["launches"], 4)}
             if executed_mult != 1.0:
                 d["executed_incl_recompute"] = round(a * executed_mult, 1)
+            if f["bytes"] > 0:
+                gbs = f["bytes"] / (f["ms"] * 1e-3) / 1e9
+                d["algorithmic_bytes_per_launch"] = round(f["bytes"] / f["launches"])
+                d["hbm_GB/s"] = round(gbs, 1)
+                d["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 4)
+                d["bound"] = "hbm" if gbs / PEAK_HBM_GBS > a / peak else "mfma"
+                t = fam_traffic.get(pmc_key or key)
+                if t:
+                    d["traffic_bytes_per_launch"] = round(t)
+                    d["traffic_over_algorithmic"] = round(t / (f["bytes"] / f["launches"]), 3)
             return d
 
         g = prof["gemm_nt"]            # plain-epilogue bf16 NT GEMMs: the dominant kernel of the step
@@ -282,11 +328,11 @@ def main() -> None:
         fam_fl = g["flops"] + sum(prof[k]["flops"] for k in fused_keys)
         fam = fam_fl / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
         families = {
-            "gemm_nt_plain": fam_of("gemm_nt", "gemm_nt_persistent EPI 1/2 (bf16 / fp32 store)"),
-            "gemm_nt_swiglu": fam_of("gemm_swiglu", "gemm_nt_persistent EPI 3 (c_fc + suv + SwiGLU)"),
-            "gemm_nt_qknorm": fam_of("gemm_qknorm", "gemm_nt_persistent EPI 4 (qkv + per-head normalise + sqk)"),
-            "gemm_nt_swiglu_bwd": fam_of("gemm_swiglu_bwd", "gemm_nt_persistent EPI 5 (mlp_c_proj dgrad + SwiGLU backward)"),
-            "gemm_tn_wgrad": fam_of("gemm_tn", "gemm_tn_persistent + slab_reduce (weight gradients)"),
+            "gemm_nt_plain": fam_of("gemm_nt", "gemm_nt_persistent EPI 1/2 (bf16 / fp32 store)", pmc_key="gemm_nt_plain"),
+            "gemm_nt_swiglu": fam_of("gemm_swiglu", "gemm_nt_persistent EPI 3 (c_fc + suv + SwiGLU)", pmc_key="gemm_nt_epi3"),
+            "gemm_nt_qknorm": fam_of("gemm_qknorm", "gemm_nt_persistent EPI 4 (qkv + per-head normalise + sqk)", pmc_key="gemm_nt_epi4"),
+            "gemm_nt_swiglu_bwd": fam_of("gemm_swiglu_bwd", "gemm_nt_persistent EPI 5 (mlp_c_proj dgrad + SwiGLU backward)", pmc_key="gemm_nt_epi5"),
+            "gemm_tn_wgrad": fam_of("gemm_tn", "gemm_tn_persistent + slab_reduce (weight gradients)", pmc_key="gemm_tn"),
             "attn_fwd": fam_of("attn_fwd", "attn_fwd_mfma (4*B*H*T^2*d)"),
             # algorithmic backward = 10*B*H*T^2*d (five products); the two-kernel form executes 14 (S and dP twice)
             "attn_bwd": fam_of("attn_bwd", "attn_bwd_dq_mfma + attn_bwd_dkv_mfma (10*B*H*T^2*d algorithmic)", 1.4),
@@ -297,7 +343,6 @@ def main() -> None:
                                                          "3 x 2*M*C*(Kl+Kg) executed)")
         families = {k: v for k, v in families.items() if v}
         weakest = min(families, key=lambda k: families[k]["frac"]) if families else None
-        traffic, traffic_src = pmc_traffic()
         # algorithmic bytes of an average plain gemm_nt launch: A [M,K] bf16 + B [N,K] bf16 + C [M,N] (4 B: fp32 outputs dominate)
         T = (cfg.image_size // cfg.local_patch_size) ** 2
         out = {
@@ -344,6 +389,8 @@ def main() -> None:
             alg = _gemm_nt_algorithmic_bytes(cfg, args.batch)
             out["roofline"]["algorithmic_bytes"] = alg
             out["roofline"]["traffic_over_algorithmic"] = round(traffic / alg, 3)
+        if world == 1:
+            out["parity"] = run_parity(model, cfg, args, X)
         if args.check:
             out["check"] = run_check(model, cfg, args, X, dev)
         if args.graph:

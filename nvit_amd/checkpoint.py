@@ -34,7 +34,10 @@ def _model_state(model) -> Dict[str, torch.Tensor]:
 
 def _numpy_safe_globals():
     """Globals a pickled `np.random.get_state()` tuple refers to (array reconstruction only, no code)."""
-    from numpy._core import multiarray as ma
+    try:
+        from numpy._core import multiarray as ma      # numpy >= 1.26 / 2.x
+    except ImportError:                                # older numpy: same function, old module path
+        from numpy.core import multiarray as ma
     allow = [ma._reconstruct, np.ndarray, np.dtype, type(np.dtype(np.uint32))]
     # files written under numpy 1.x name the same function through the old module path
     allow.append((ma._reconstruct, "numpy.core.multiarray._reconstruct"))
@@ -69,13 +72,15 @@ def load_checkpoint(path, device="cuda", optimizer_factory=None, restore_rng: bo
     """-> (model, optimizer | None, checkpoint dict).  `optimizer_factory(model)` builds the optimizer whose state is
     then restored (e.g. `lambda m: m.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")`)."""
     from .model import ViT
+    import pickle
+    allow = _numpy_safe_globals()      # built outside the try: an import problem here is not a property of the file
     try:
-        with torch.serialization.safe_globals(_numpy_safe_globals()):
+        with torch.serialization.safe_globals(allow):
             ck = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception as e:
+    except (pickle.UnpicklingError, RuntimeError) as e:   # (missing / unreadable files raise their own OSError untouched)
         if not trusted:
-            raise RuntimeError(f"{path}: not loadable with weights_only=True ({type(e).__name__}); pass trusted=True "
-                               "only for a file you wrote yourself") from e
+            raise RuntimeError(f"{path}: not loadable with weights_only=True ({type(e).__name__}: {e}); pass "
+                               "trusted=True only for a file you wrote yourself") from e
         ck = torch.load(path, map_location="cpu", weights_only=False)
     model = ViT(ViTConfig(**ck["model_args"]))
     res = model.load_state_dict(ck["model"], strict=False)

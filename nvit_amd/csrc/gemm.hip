@@ -391,7 +391,10 @@ extern "C" int nvit_gemm_nt(int dt, const void* A, int lda, const void* B, int l
   const long long blocks = (long long)cdiv(M, BM) * g.tiles_n;
   NVIT_REQUIRE(blocks < (1ll << 31), "gemm_nt: grid too large");
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(dt == NVIT_F32 ? NVIT_KID_GEMM_F32 : NVIT_KID_GEMM_NT, 2.0 * M * N * K, 0.0, s);
+  // algorithmic bytes: A and B read once, C written once (read as well when accumulating)
+  const double nt_bytes = (double)es * ((double)M * K + (double)N * K) +
+                          (double)(out_dt == NVIT_F32 ? 4 : 2) * M * N * (accumulate ? 2.0 : 1.0);
+  ProfScope ps(dt == NVIT_F32 ? NVIT_KID_GEMM_F32 : NVIT_KID_GEMM_NT, 2.0 * M * N * K, nt_bytes, s);
   {
     // large problems: persistent kernels (gemm_p.hip), 256x256 tiles when N allows, else 256x128.
     // NVIT_GEMM_NT_IMPL=0 forces the 128x128 kernel, NVIT_GEMM_NT_TILE=128|256 forces a tile width.
@@ -470,7 +473,9 @@ extern "C" int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int l
   g.tiles_k = cdiv(K, BM);
   dim3 grid((unsigned)(cdiv(N, BN) * g.tiles_k), (unsigned)splits);
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(dt == NVIT_F32 ? NVIT_KID_GEMM_F32 : NVIT_KID_GEMM_TN, 2.0 * Mred * (double)N * K, 0.0, s);
+  // algorithmic bytes: both operands read once, the fp32 gradient written once (read as well when accumulating)
+  const double tn_bytes = (double)es * Mred * ((double)N + K) + 4.0 * N * K * (accumulate ? 2.0 : 1.0);
+  ProfScope ps(dt == NVIT_F32 ? NVIT_KID_GEMM_F32 : NVIT_KID_GEMM_TN, 2.0 * Mred * (double)N * K, tn_bytes, s);
   bool done = false;
   {
     // big 256-aligned weight shapes: persistent 256x256 kernel (gemm_tn_p.hip); NVIT_GEMM_TN_IMPL=0 disables
@@ -529,7 +534,8 @@ extern "C" int nvit_gemm_nt_swiglu(int dt, const void* A, int lda, const void* B
   g.gs = gs;
   g.gscale = gscale;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_GEMM_SWIGLU, 2.0 * M * (2.0 * F) * K, 0.0, s);
+  // algorithmic bytes: A, B read; raw uv [M,2F] and gated x [M,F] written (bf16)
+  ProfScope ps(NVIT_KID_GEMM_SWIGLU, 2.0 * M * (2.0 * F) * K, 2.0 * ((double)M * K + 2.0 * F * K + 3.0 * M * F), s);
   return nvit_gemm_nt_fused_launch(g, 3, s);
 }
 
@@ -560,7 +566,9 @@ extern "C" int nvit_gemm_nt_swiglu_bwd(int dt, const void* A, int lda, const voi
   g.gscale = gscale;
   g.part = gs ? part : nullptr;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_GEMM_SWIGLU_BWD, 2.0 * M * (double)F * K, 0.0, s);
+  // algorithmic bytes: A, B and the saved raw uv [M,2F] read; d(uv) [M,2F] written (bf16) - this kernel moves 4 bytes per
+  // MAC-column pair and is judged against HBM as well as against the MFMA peak (bench.py roofline.families)
+  ProfScope ps(NVIT_KID_GEMM_SWIGLU_BWD, 2.0 * M * (double)F * K, 2.0 * ((double)M * K + (double)F * K + 4.0 * M * F), s);
   return nvit_gemm_nt_fused_launch(g, 5, s);
 }
 
@@ -598,6 +606,8 @@ extern "C" int nvit_gemm_nt_qknorm(int dt, const void* A, int lda, const void* B
   g.Ttok = T;
   g.H = H;
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_GEMM_QKNORM, 2.0 * M * (double)(nparts * C) * K, 0.0, s);
+  // algorithmic bytes: A, B read; nparts head tensors [M,C] written (bf16)
+  ProfScope ps(NVIT_KID_GEMM_QKNORM, 2.0 * M * (double)(nparts * C) * K,
+               2.0 * ((double)M * K + (double)nparts * C * K + (double)nparts * M * C), s);
   return nvit_gemm_nt_fused_launch(g, 4, s);
 }

@@ -69,9 +69,14 @@ class RMSNorm(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         if not x.is_cuda:
             raise RuntimeError("RMSNorm runs only on the HIP device (no CPU fallback)")
-        if x.dtype != torch.float32:
-            raise RuntimeError("RMSNorm: fp32 input expected (the reference computes it in fp32)")
-        return _RMSNormFn.apply(x, self.weight, self.eps)
+        if x.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+            raise RuntimeError(f"RMSNorm: floating-point input expected, got {x.dtype}")
+        if x.dtype == torch.float32:
+            return _RMSNormFn.apply(x, self.weight, self.eps)
+        # reference model.py:176-182: computed in fp32, the normalised value cast back to the input dtype BEFORE the
+        # weight multiply (torch type promotion then decides the output dtype)
+        ones = torch.ones_like(self.weight)
+        return self.weight * _RMSNormFn.apply(x, ones, self.eps).to(x.dtype)
 
 
 # --------------------------------------------------------------------------------------------
@@ -1012,6 +1017,8 @@ class ViT(nn.Module):
             aux["local_quantization"] = HuberFn.apply(lrep2, loc)
             aux["global_quantization"] = HuberFn.apply(grep2, glo)
             x, x_lo = self.cross_attention._run(local_new, global_new)
+            if self._taps is not None:
+                self._taps["lidx"], self._taps["gidx"] = local_idx.detach(), global_idx.detach()
         else:
             x, x_lo = self.cross_attention._run(loc, glo, loc_lo, glo_lo)
         taps = self._taps

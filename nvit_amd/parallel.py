@@ -79,6 +79,7 @@ class DataParallel(nn.Module):
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.bucket_cap = int(bucket_cap_mb * 1024 * 1024)
+        self._avg = dist.get_backend(process_group) == "nccl"
         self._sync = True
         self._buckets: Optional[List[_Bucket]] = None   # built after the first backward
         self._bucket_of = {}
@@ -96,8 +97,7 @@ class DataParallel(nn.Module):
         if hasattr(module, "_node_sync"):
             def _sync_nodes(*tensors):
                 for t in tensors:
-                    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
-                    t.div_(self.world)
+                    self._mean_all_reduce(t, async_op=False)
             object.__setattr__(module, "_node_sync", _sync_nodes)
         self._params = [p for p in module.parameters() if p.requires_grad]
         for p in self._params:
@@ -147,8 +147,16 @@ class DataParallel(nn.Module):
         if self._xg is not None:   # direct xGMI collective: the whole symmetric buffer goes at the end of backward
             b.handle = _Done()
             return
-        b.flat.div_(self.world)
-        b.handle = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        b.handle = self._mean_all_reduce(b.flat, async_op=True)
+
+    def _mean_all_reduce(self, t: torch.Tensor, async_op: bool):
+        """Mean over ranks.  On RCCL the 1/N is part of the collective (ReduceOp.AVG: no extra pass over the bucket -
+        a separate `div_` was 479 MB of read + write per Base step on the critical stream); gloo (CPU tests and the
+        one-GPU DP tests) has no AVG, there the scale runs before the sum."""
+        if self._avg:
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+        t.div_(self.world)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def _ordered_used(self) -> List[nn.Parameter]:
         """Reverse registration order (= the order backward produces gradients in), except that weights whose gradients
@@ -245,8 +253,7 @@ class DataParallel(nn.Module):
         if self._xg is not None:
             self._xg.all_reduce_(1.0 / self.world)
         for p in self._late:
-            p.grad.div_(self.world)
-            dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=self.group)
+            self._mean_all_reduce(p.grad, async_op=False)
         self._late = []
         for b in self._buckets:
             if b.handle is not None:

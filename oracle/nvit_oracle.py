@@ -28,7 +28,7 @@ golden vectors produced by importing the real reference on CPU
 (oracle/make_golden.py, run in the build container; fixtures in tests/golden/),
 including the known-answer record of SURVEY.md §9.3.
 
-`lowp` hook: when not None it is applied to every GEMM operand (activations and
+`lowp` hook (bf16_round, or a KernelRounding instance): when not None it is applied to every GEMM operand (activations and
 weights) and to the un-normalised softmax probabilities exp(s - rowmax) (the
 operand a fused attention kernel feeds its second product), emulating "bf16 MFMA
 operands, fp32 accumulate" so the bf16 HIP path can be compared at a tight
@@ -50,6 +50,37 @@ def bf16_round(t: Tensor) -> Tensor:
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+class KernelRounding:
+    """bf16-operand emulation that rounds at the points where the HIP kernels round (still a CPU computation over the
+    reference's algorithm; what changes is WHICH fp32 value each bf16 operand is the rounding of):
+
+      * attention (head dim 64, the MFMA kernels): `nvit_attn_fwd_bounded` takes the probabilities relative to the
+        score bound of the head, tb = sqrt(d)*log2(e)*max_d(sqk*c_q)^2, instead of the row maximum: the second
+        product's operand is bf16(exp2(s*log2e - tb)), and the row sum that normalises the output is the fp32 sum of
+        those ROUNDED values (it comes out of the matrix pipe as one extra ones-row).  The factor between the two
+        conventions is not a power of two, so every probability rounds independently of the row-maximum form.
+      * on the fused path (n_embd % 256 == 0) the q projection leaves its GEMM epilogue pre-scaled by sqrt(d)*log2(e)
+        (one rounding of q_hat*prescale instead of rounding q_hat and scaling the fp32 score).
+    `acc64=True` additionally accumulates every matrix product in float64 (same operand roundings, different summation
+    order/accuracy): the distance between the two is the noise floor of 'same rounding points, other summation order'.
+    With attn_conv="rowmax" and acc64=False this is exactly `bf16_round`."""
+
+    def __init__(self, attn_conv: str = "bound", acc64: bool = False) -> None:
+        assert attn_conv in ("bound", "rowmax")
+        self.attn_conv = attn_conv
+        self.acc64 = acc64
+
+    def __call__(self, t: Tensor) -> Tensor:
+        return bf16_round(t)
+
+
+def _mm(a: Tensor, b: Tensor, lowp: LowP) -> Tensor:
+    """a @ b with the accumulation precision the rounding mode asks for."""
+    if getattr(lowp, "acc64", False):
+        return (a.double() @ b.double()).float()
+    return a @ b
+
+
 def _lp(t: Tensor, lowp: LowP) -> Tensor:
     return t if lowp is None else lowp(t)
 
@@ -59,7 +90,7 @@ def nrm(x: Tensor) -> Tensor:
 
 
 def linear(x: Tensor, w: Tensor, b: Optional[Tensor], lowp: LowP) -> Tensor:
-    y = _lp(x, lowp) @ _lp(w, lowp).t()
+    y = _mm(_lp(x, lowp), _lp(w, lowp).t(), lowp)
     return y if b is None else y + b
 
 
@@ -97,7 +128,19 @@ def attend(q: Tensor, k: Tensor, v: Tensor, s_eff: Tensor, H: int, lowp: LowP) -
     qh = s * nrm(heads(q, H))
     kh = s * nrm(heads(k, H))
     vh = heads(v, H)
-    scores = (_lp(qh, lowp) @ _lp(kh, lowp).transpose(-1, -2)) * math.sqrt(d)
+    if lowp is not None and getattr(lowp, "attn_conv", "rowmax") == "bound" and d == 64:
+        # the MFMA kernels' rounding points (see KernelRounding): scores in log2 units, probabilities relative to the bound
+        log2e = 1.4426950408889634
+        c2t = math.sqrt(d) * log2e
+        qpre = c2t if C % 256 == 0 else 1.0           # fused q/k-normalise GEMM epilogue folds the factor into q's scale
+        tb = c2t * s_eff.reshape(H, d).abs().max(dim=-1).values ** 2          # [H]
+        if float(tb.max()) <= 60.0:
+            qs = lowp(nrm(heads(q, H)) * (s * qpre))
+            z = _mm(qs, lowp(kh).transpose(-1, -2), lowp) * (c2t / qpre) - tb.reshape(1, H, 1, 1)
+            pt = lowp(torch.exp2(z))
+            o = _mm(pt, lowp(vh), lowp) / pt.sum(dim=-1, keepdim=True)
+            return o.permute(0, 2, 1, 3).reshape(B, T, C)
+    scores = _mm(_lp(qh, lowp), _lp(kh, lowp).transpose(-1, -2), lowp) * math.sqrt(d)
     if lowp is None:
         o = torch.softmax(scores, dim=-1) @ vh
     else:
@@ -105,7 +148,7 @@ def attend(q: Tensor, k: Tensor, v: Tensor, s_eff: Tensor, H: int, lowp: LowP) -
         # exp(s - rowmax), as in every fused (flash-style) attention kernel incl. the reference's SDPA under autocast;
         # the row sum that normalises the output is taken in fp32 from the unrounded values
         pt = torch.exp(scores - scores.max(dim=-1, keepdim=True).values)
-        o = (lowp(pt) @ lowp(vh)) / pt.sum(dim=-1, keepdim=True)
+        o = _mm(lowp(pt), lowp(vh), lowp) / pt.sum(dim=-1, keepdim=True)
     return o.permute(0, 2, 1, 3).reshape(B, T, C)
 
 

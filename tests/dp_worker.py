@@ -81,7 +81,7 @@ def main():
         flat = torch.cat([t.flatten() for t in g.values()]).cpu()
         both = [torch.empty_like(flat) for _ in range(world)]
         dist.all_gather(both, flat)
-        res[f"ranks_equal_step{step}"] = bool(torch.equal(both[0], both[1]))
+        res[f"ranks_equal_step{step}"] = all(torch.equal(both[0], b) for b in both[1:])
         res[f"aligned_step{step}"] = all(p.grad.data_ptr() % 16 == 0 for p in m.parameters() if p.grad is not None)
         # fused clip + AdamW + renorm on the bucket-view gradients
         gn = opt.step_fused(dp, 1.0)
@@ -95,12 +95,12 @@ def main():
         nodes = torch.cat([m.local_kohonen.nodes.detach().flatten(), m.global_kohonen.nodes.detach().flatten()]).cpu()
         both = [torch.empty_like(nodes) for _ in range(world)]
         dist.all_gather(both, nodes)
-        res["nodes_equal"] = bool(torch.equal(both[0], both[1]))
+        res["nodes_equal"] = all(torch.equal(both[0], b) for b in both[1:])
     # parameters after 3 optimizer steps: identical on both ranks, and equal to the single-process run
     flat = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()
     both = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
-    res["params_equal_across_ranks"] = bool(torch.equal(both[0], both[1]))
+    res["params_equal_across_ranks"] = all(torch.equal(both[0], b) for b in both[1:])
     if ref is not None:
         res["param_err_vs_single_process"] = max(
             (a.detach() - b.detach()).abs().max().item() for a, b in zip(m.parameters(), ref.parameters()))

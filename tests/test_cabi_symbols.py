@@ -5,6 +5,8 @@ import os
 import re
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -64,3 +66,24 @@ def test_model_refuses_to_run_without_a_gpu_tensor():
     from nvit_amd.train import normalize_matrices
     with pytest.raises(RuntimeError):
         normalize_matrices(m)
+
+
+def test_product_build_rejects_probe_switches(tmp_path):
+    """The timing-probe switches (NVIT_PROBE_*: cut-down kernels whose results are garbage by design) cannot leak into
+    libnvit_hip.so: the Makefile defines NVIT_PRODUCT_BUILD and common.h turns any probe switch into a build error."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "nvit_amd", "csrc")
+    assert "-DNVIT_PRODUCT_BUILD" in open(os.path.join(csrc, "Makefile")).read()
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = tmp_path / "probe_guard.hip"
+    src.write_text(f'#include "{csrc}/common.h"\nint main() {{ return 0; }}\n')
+    base = [hipcc, "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", "-DNVIT_PRODUCT_BUILD", str(src)]
+    ok = subprocess.run(base, capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr[-500:]
+    for sw in ("NVIT_PROBE_NO_DMA", "NVIT_PROBE_ATTN_NOEXP", "NVIT_PROBE_V2_NO_DMA"):
+        bad = subprocess.run(base + [f"-D{sw}"], capture_output=True, text=True)
+        assert bad.returncode != 0 and "NVIT_PROBE" in bad.stderr, sw

@@ -376,10 +376,12 @@ def test_base_config_full_size_properties():
     assert torch.isfinite(full).all()
     # (a batch of 4 and a batch of 1 take different kernel variants - persistent/fused vs 128-tile/unfused - so the
     #  comparison is at bf16 tolerance, not bitwise)
-    assert (full - singles).abs().max().item() < 4e-3, "batch rows are not independent"
+    bs = (full - singles).abs().max().item()
+    print(f"[base full size] batch of 4 vs four single-image calls (different kernel variants): max|dlogit| = {bs:.3e}")
+    assert bs < 1.5e-3, "batch rows are not independent"
     d32 = (full[:2] - full32).abs().max().item()
     print(f"[base full size] bf16 vs fp32 mode max|dlogit| = {d32:.3e} (|logit|max {full32.abs().max().item():.3f})")
-    assert d32 < 2e-2
+    assert d32 < 4e-3      # = the operand-rounding cost measured against the oracle (2.7e-3 at Base) + margin
     opt = m.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")
     losses = []
     for _ in range(3):
@@ -484,6 +486,20 @@ def test_kohonen_step_under_nan_poison():
     assert got == ref, (got, ref)
 
 
+def _record_margin(name, batch, vals):
+    """Measured bf16 margins of the full-size tests, appended to gpurun_out/parity_margins.json on the GPU box (a copy is
+    committed under profiles/ each round, so a drift of the ABSOLUTE errors stays visible even while the tests pass)."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_margins.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[f"{name}_b{batch}"] = {k: float(f"{v:.4e}") for k, v in vals.items()}
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
 def _oracle_with_taps(cfg, X, y, lowp):
     p = O.make_params(formula_state_dict(cfg))
     O.renorm_(p, cfg)
@@ -519,11 +535,23 @@ def _full_size_bf16_parity(name, batch, grads: bool):
     cfg = named_config(name)
     X, y = synthetic_batch(cfg, batch)
     p32, l32, loss32, t32 = _oracle_with_taps(cfg, X, y, None)
-    pem, lem, lossem, tem = _oracle_with_taps(cfg, X, y, O.bf16_round)
+    # the bf16-operand emulation rounds where the HIP kernels round (O.KernelRounding: probabilities relative to the
+    # score bound, row sum over the rounded values, q pre-scaled before its rounding); its acc64 twin differs from it in
+    # summation precision only and measures how far two evaluations with IDENTICAL rounding points drift apart
+    pem, lem, lossem, tem = _oracle_with_taps(cfg, X, y, O.KernelRounding("bound"))
+    with torch.no_grad():
+        pf = O.make_params(formula_state_dict(cfg))
+        O.renorm_(pf, cfg)
+        l64, _ = O.forward(pf, cfg, X, O.KernelRounding("bound", acc64=True), training=True)
+        lrm, _ = O.forward(pf, cfg, X, O.bf16_round, training=True)
+        del pf
     lmax = l32.abs().max().item()
     d_emu = (lem - l32).abs().max().item()
+    floor = (lem - l64).abs().max().item()
     print(f"[{name} B={batch}] oracle: |logit|max {lmax:.3f}; bf16-operand oracle vs fp32 oracle {d_emu:.3e} "
-          f"(the intrinsic cost of bf16 MFMA operands at this size)")
+          f"(the intrinsic cost of bf16 MFMA operands at this size); the same emulation with float64 accumulation "
+          f"moves by {floor:.3e} (summation order alone), the row-maximum softmax convention by "
+          f"{(lem - lrm).abs().max().item():.3e}")
     # ---- fp32 mode: the 1e-5 bar, gradient norms to 1e-3
     m = build(cfg, "fp32", True).train()
     lg, loss, taps = _hip_with_taps(m, X, y)
@@ -566,9 +594,8 @@ def _full_size_bf16_parity(name, batch, grads: bool):
         print("                                         HIP-vs-fp32: " + " ".join(f"{v:.1e}" for v in le32))
         print("                                         emu-vs-fp32: " + " ".join(f"{v:.1e}" for v in lo))
         results[tag] = (lb, e32, eem)
-        # the bar: within 1e-3 (or 5e-4 of the logit range, whichever is larger: Large has |logit|max 2.7) of the oracle
-        # that rounds the same GEMM operands to bf16 ...
-        assert eem < max(1e-3, 5e-4 * lmax), (tag, eem)
+        # the bar: within 1e-3 of the oracle that rounds the same operands at the same points ...
+        assert eem < 1e-3, (tag, eem, floor)
         # ... and no further from the fp32 oracle than that emulation is: the whole logit field in rms (+5 %), and its
         # maximum (one of ~2 000 values of two superposed error fields; it moves by up to 13 % with nothing but the
         # summation order of the kernels, measured over the round's kernel variants) within 15 % + 2e-4
@@ -594,6 +621,8 @@ def _full_size_bf16_parity(name, batch, grads: bool):
                 assert ratio < (0.02 if a.numel() > 16 else 0.25), (tag, n, ratio)
                 worst_ratio = max(worst_ratio, ratio if a.numel() > 16 else 0.0)
             print(f"      gradients vs fp32 oracle: worst cosine {worst_cos:.6f}, worst norm ratio error {worst_ratio:.2e}")
+    _record_margin(name, batch, dict(hip_vs_emulation=results["default dispatch"][2], hip_vs_fp32=results["default dispatch"][1],
+                                     emulation_vs_fp32=d_emu, summation_floor=floor, logit_max=lmax))
     a, b = results["default dispatch"][0], results["persistent kernels forced"][0]
     print(f"   bf16 mode: default dispatch vs persistent kernels {(a - b).abs().max().item():.3e}")
     assert (a - b).abs().max().item() < 1e-3
@@ -692,7 +721,7 @@ def test_base_kohonen_config_c5_vs_cpu_oracle():
     # bf16 mode (fresh weights: the SOM nodes were updated in place by the forward above)
     pe = O.make_params(formula_state_dict(cfg))
     O.renorm_(pe, cfg)
-    lem, _, _ = O.loss_and_grads(pe, cfg, X, y, lowp=O.bf16_round, step=1, want_aux=True)
+    lem, _, _ = O.loss_and_grads(pe, cfg, X, y, lowp=O.KernelRounding("bound"), step=1, want_aux=True)
     mb = build(cfg, "bf16", True).train()
     with torch.no_grad():
         lb, auxb = mb(X.cuda())
@@ -701,7 +730,18 @@ def test_base_kohonen_config_c5_vs_cpu_oracle():
     lmax = l32.abs().max().item()
     print(f"   bf16 mode: max|dlogit| vs bf16-operand oracle {eem:.3e}, vs fp32 oracle {e32:.3e}; oracle bf16-operand vs fp32 "
           f"{d_emu:.3e}")
-    # (the Kohonen branch feeds un-normalised node vectors, |repr| ~ sqrt(C) = 28, through three cross-attention calls:
-    #  its operand-rounding noise is larger in absolute terms - measured 1.6e-3 vs the emulation, 2.6e-3 vs fp32,
-    #  emulation vs fp32 2.1e-3)
-    assert eem < 2e-3 and e32 < d_emu + 1e-3
+    # Attribution (tools/parity_attribution.py base_k 2): the SOM indices agree with the oracle on all
+    # 2 x 1568 tokens, and at this configuration two CPU evaluations with IDENTICAL rounding points that differ only in
+    # summation precision (float32 vs float64 accumulation) already differ by 1.06e-3 in the logits - the residual is
+    # the trunk's sensitivity to summation order (it stays 8.8e-4 with the whole cross-attention block computed exactly),
+    # not a kernel family.  The bar is therefore tied to that floor, measured here, instead of a constant.
+    pf = O.make_params(formula_state_dict(cfg))
+    O.renorm_(pf, cfg)
+    with torch.no_grad():
+        l64, _ = O.forward(pf, cfg, X, O.KernelRounding("bound", acc64=True), training=True, step=1)
+    floor = (lem - l64).abs().max().item()
+    print(f"   summation-order floor of the emulation itself (fp32 vs fp64 accumulation, same roundings): {floor:.3e}")
+    _record_margin("base_k", 2, dict(hip_vs_emulation=eem, hip_vs_fp32=e32, emulation_vs_fp32=d_emu, summation_floor=floor,
+                                     logit_max=lmax))
+    assert eem < max(1e-3, 1.5 * floor), (eem, floor)
+    assert e32 < d_emu + 1e-3, (e32, d_emu)

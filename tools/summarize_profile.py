@@ -132,7 +132,25 @@ def main():
         nl = sum(pm["FETCH_SIZE"][n][0] for n in fam) if "FETCH_SIZE" in pm else 0
         fetch = sum(pm["FETCH_SIZE"][n][1] for n in fam) if "FETCH_SIZE" in pm else 0.0
         write = sum(pm["WRITE_SIZE"][n][1] for n in fam) if "WRITE_SIZE" in pm else 0.0
-        js = {"family": "gemm_nt (plain epilogue)", "launches": nl, "fetch_bytes_per_launch_corrected": 2.0 * fetch * 1024 / max(1, nl),
+        # every GEMM family bench.py lists (same correction): bytes per launch
+        def fam_traffic(pred):
+            ks = [n for n in names if pred(n)]
+            nl_ = sum(pm["FETCH_SIZE"][n][0] for n in ks) if "FETCH_SIZE" in pm else 0
+            fe_ = sum(pm["FETCH_SIZE"][n][1] for n in ks) if "FETCH_SIZE" in pm else 0.0
+            wr_ = sum(pm["WRITE_SIZE"][n][1] for n in ks) if "WRITE_SIZE" in pm else 0.0
+            return (2.0 * fe_ + wr_) * 1024 / nl_ if nl_ else None
+        families = {"gemm_nt_plain": fam_traffic(lambda n: n in fam),
+                    "gemm_nt_epi3": fam_traffic(lambda n: n.startswith("gemm_nt") and "EPI=3" in n),
+                    "gemm_nt_epi4": fam_traffic(lambda n: n.startswith("gemm_nt") and "EPI=4" in n),
+                    "gemm_nt_epi5": fam_traffic(lambda n: n.startswith("gemm_nt") and "EPI=5" in n),
+                    "gemm_tn": fam_traffic(lambda n: n.startswith("gemm_tn_persistent")),
+                    "attn_fwd": fam_traffic(lambda n: n.startswith("attn_fwd")),
+                    "attn_bwd_dq": fam_traffic(lambda n: n.startswith("attn_bwd_dq")),
+                    "attn_bwd_dkv": fam_traffic(lambda n: n.startswith("attn_bwd_dkv")),
+                    "lerp_fwd": fam_traffic(lambda n: n.startswith("lerp_fwd")),
+                    "lerp_bwd": fam_traffic(lambda n: n.startswith("lerp_bwd"))}
+        families = {k: v for k, v in families.items() if v}
+        js = {"family": "gemm_nt (plain epilogue)", "families": families, "launches": nl, "fetch_bytes_per_launch_corrected": 2.0 * fetch * 1024 / max(1, nl),
               "write_bytes_per_launch": write * 1024 / max(1, nl),
               "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024 / max(1, nl),
               "note": "L2<->fabric bytes (Infinity-Cache hits are included by these counters); FETCH_SIZE x2 per the gfx950 correction",
