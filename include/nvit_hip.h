@@ -343,6 +343,32 @@ int64_t nvit_xgmi_chunk(int64_t n, int nranks);
 int nvit_xgmi_reduce_scatter(const int64_t* peer_ptrs, int nranks, int rank, int64_t n, float scale, void* stream);
 int nvit_xgmi_all_gather(const int64_t* peer_ptrs, int nranks, int rank, int64_t n, void* stream);
 
+/* Device-synchronised form of the same collective (replaces the NCCL communicator the reference's DDP wrapper drives,
+ * nvit/train.py:438-446, with phase flags that live on the devices): no host barrier between "gradients written",
+ * reduce-scatter and all-gather, several regions ("slots", one per gradient bucket) in flight at once, every call just
+ * kernel launches on `stream`.  Each rank owns a flag block in uncached device memory:
+ *   nvit_xgmi_flag_bytes(nslots)            size of a flag block (0 for a bad slot count; at most 64 slots)
+ *   nvit_xgmi_flags_alloc(nslots, &p, h)    allocate + zero this rank's block, h = 64-byte IPC handle to send to the peers
+ *   nvit_xgmi_flags_open(h, &p) / _close(p) map / unmap a peer's block;  nvit_xgmi_flags_free(p) frees the own block
+ *   nvit_xgmi_flags_error(own, nslots, &w, stream)   synchronises `stream`, w = 0 or (code << 8 | slot + 1) of the first
+ *                                           wait that timed out (20 s): 1 reduce-scatter, 2 all-gather, 3 wait_gathered
+ * flag_ptrs: HOST array of nranks device pointers to the flag blocks ([rank] = own).  Region = elements [off, off + n) of
+ * every symmetric buffer (multiples of 4), chunked by nvit_xgmi_chunk(n, nranks); `epoch` = number of this call for the
+ * slot, from 1, the same on every rank.  A region may be rewritten only after nvit_xgmi_wait_gathered has been enqueued
+ * for its slot (slots / epochs: DEVICE arrays of nwait entries) on the stream that rewrites it. */
+int64_t nvit_xgmi_flag_bytes(int nslots);
+int nvit_xgmi_flags_alloc(int nslots, void** dev_ptr, void* ipc_handle_out);
+int nvit_xgmi_flags_open(const void* ipc_handle, void** dev_ptr);
+int nvit_xgmi_flags_close(void* dev_ptr);
+int nvit_xgmi_flags_free(void* dev_ptr);
+int nvit_xgmi_flags_error(const void* own_flags, int nslots, unsigned* out, void* stream);
+int nvit_xgmi_reduce_scatter_sync(const int64_t* peer_ptrs, const int64_t* flag_ptrs, int nranks, int rank, int nslots,
+                                  int slot, unsigned epoch, int64_t off, int64_t n, float scale, void* stream);
+int nvit_xgmi_all_gather_sync(const int64_t* peer_ptrs, const int64_t* flag_ptrs, int nranks, int rank, int nslots, int slot,
+                              unsigned epoch, int64_t off, int64_t n, void* stream);
+int nvit_xgmi_wait_gathered(const int64_t* flag_ptrs, int nranks, int rank, int nslots, const int* slots,
+                            const unsigned* epochs, int nwait, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

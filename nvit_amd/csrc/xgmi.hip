@@ -9,9 +9,31 @@
 //   all-gather    : rank r copies chunk j from rank j's buffer into its own, for every j != r (again S/N per link).
 // Both are plain grid-stride kernels of 16-byte accesses with all N peer loads of an element group in flight together.
 // The buffers are "symmetric": the same layout on every rank, exported once as IPC handles (host side:
-// nvit_amd/xgmi.py).  Phase separation (all gradients written -> reduce-scatter -> all-gather -> buffers reusable) is the
-// caller's job; the Python wrapper uses stream synchronisation + a host barrier, which is correct everywhere and is what
-// could be verified without a multi-GPU node (ranks sharing one device).
+// nvit_amd/xgmi.py).
+//
+// Phase separation comes in two forms:
+//   * nvit_xgmi_reduce_scatter / nvit_xgmi_all_gather: plain kernels, the CALLER separates the phases (stream
+//     synchronisation + a host barrier of the process group);
+//   * nvit_xgmi_reduce_scatter_sync / nvit_xgmi_all_gather_sync / nvit_xgmi_wait_gathered: the phases are separated ON
+//     THE DEVICE by flags, so a call is just two kernel launches on a stream: no host round trip, several regions
+//     ("slots": one per gradient bucket) in flight at once, overlappable with backward.  Every rank owns a small flag
+//     block in UNCACHED device memory (hipDeviceMallocUncached: coherent across devices without cache maintenance),
+//     exported over IPC like the data buffer; a rank announces a phase by STORING its epoch into the flag blocks of
+//     all ranks (a remote store over the link) and waits by polling its OWN block (local loads):
+//        ready[slot][r]    = e   rank r's region is completely written          (set when r's reduce-scatter starts:
+//                                                                                   stream order puts it after the writers)
+//        reduced[slot][r]  = e   chunk r of rank r's region holds the reduced sum (set by the last block of r's
+//                                reduce-scatter, after a system-scope release of its stores); it also means r has
+//                                finished READING chunk r of every other region
+//        gathered[slot][r] = e   rank r has finished reading every other rank's reduced chunk
+//     reduce-scatter waits for ready[*], all-gather for reduced[*], and nvit_xgmi_wait_gathered (issued before the
+//     region is written again) for gathered[*].  Data is only ever WRITTEN locally and READ remotely; readers take a
+//     system-scope acquire after their wait (stale remote lines in their caches), writers a system-scope release before
+//     their flag.  Epochs count the calls per slot (same on every rank); every spin is bounded by wall time (the
+//     100 MHz constant clock) and reports a timeout through the flag block's error word instead of hanging.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -102,5 +124,258 @@ extern "C" int nvit_xgmi_all_gather(const int64_t* peer_ptrs, int nranks, int ra
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(xgmi_all_gather_kernel, dim3(blocks), dim3(256), 0, s, p, nranks, rank, (long long)chunk, (long long)n);
   NVIT_CHECK_LAUNCH("xgmi_all_gather");
+  return NVIT_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Device-synchronised form (see the header comment).  Flag block layout (32-bit words, one block per rank):
+//   [0 .. 3*S*8)      phase p (0 ready, 1 reduced, 2 gathered), slot s, source rank r  ->  word (p*S + s)*8 + r
+//   [3*S*8 .. +S)     per-slot arrival counter of this rank's own kernels (last-block detection), returns to 0
+//   [3*S*8 + S]       error word: 0, or (code << 8 | slot + 1) of the first timed-out wait
+namespace {
+
+constexpr int XGMI_MAX_SLOTS = 64;
+constexpr unsigned long long XGMI_TIMEOUT_TICKS = 20ull * 100000000ull;   // 20 s of the 100 MHz constant clock
+
+struct XgmiFlags {
+  unsigned* f[XGMI_MAX_RANKS];   // this process's mappings of every rank's flag block ([rank] = own)
+};
+
+__device__ __forceinline__ unsigned* flag_word(unsigned* base, int S, int phase, int slot, int r) {
+  return base + ((size_t)phase * S + slot) * XGMI_MAX_RANKS + r;
+}
+
+// thread 0 of the block: wait until flags[phase][slot][r] == epoch for every r in the mask; false on timeout
+__device__ __forceinline__ bool wait_flags(unsigned* own, int S, int phase, int slot, int nranks, unsigned skip_rank,
+                                           unsigned epoch, int code) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (int r = 0; r < nranks; ++r) {
+    if ((unsigned)r == skip_rank) continue;
+    unsigned* w = flag_word(own, S, phase, slot, r);
+    // (>= in wrap-around arithmetic: a peer can never be a whole call ahead on a slot - it would have had to see this
+    //  rank's `gathered` flag of the current call - but equality is not what the protocol means)
+    while ((int)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) < 0) {
+      __builtin_amdgcn_s_sleep(32);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > XGMI_TIMEOUT_TICKS) {
+        unsigned* err = own + (size_t)3 * S * XGMI_MAX_RANKS + S;
+        __hip_atomic_compare_exchange_strong(err, (unsigned[]){0u}, (unsigned)(code << 8 | (slot + 1)), __ATOMIC_RELAXED,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return false;
+      }
+    }
+  }
+  return true;
+}
+
+// all threads of the block: every wave drains its stores, the block's last arrival publishes flags[phase][slot][rank]
+// = epoch into EVERY rank's block (own included) behind a system-scope release
+__device__ __forceinline__ void publish_when_last(const XgmiFlags& fl, int S, int phase, int slot, int nranks, int rank,
+                                                  unsigned epoch) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave: its stores have left the CU
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");      // system scope: write this XCD's dirty lines back
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the fence's own wait may be dropped by the compiler)
+    unsigned* cnt = fl.f[rank] + (size_t)3 * S * XGMI_MAX_RANKS + slot;
+    const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == gridDim.x - 1) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int j = 0; j < nranks; ++j)
+        __hip_atomic_store(flag_word(fl.f[j], S, phase, slot, rank), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void xgmi_rs_sync_kernel(XgmiPeers peers, XgmiFlags fl, int S, int slot, unsigned epoch,
+                                                           int nranks, int rank, long long off, long long c0,
+                                                           long long c1, float scale) {
+  __shared__ int ok_s;
+  if (blockIdx.x == 0 && threadIdx.x < (unsigned)nranks)   // this rank's region is complete (stream order): tell everyone
+    __hip_atomic_store(flag_word(fl.f[threadIdx.x], S, 0, slot, rank), epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) {
+    ok_s = wait_flags(fl.f[rank], S, 0, slot, nranks, 0xffffffffu, epoch, 1) ? 1 : 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");        // drop stale copies of the peers' lines (system scope)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (ok_s) {
+    const long long n4 = (c1 - c0) >> 2;
+    float* out = peers.p[rank] + off + c0;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+      f32x4 v[XGMI_MAX_RANKS];
+#pragma unroll
+      for (int r = 0; r < XGMI_MAX_RANKS; ++r)
+        if (r < nranks) v[r] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(peers.p[r] + off + c0) + i);
+      f32x4 acc = v[0];
+#pragma unroll
+      for (int r = 1; r < XGMI_MAX_RANKS; ++r)
+        if (r < nranks) acc += v[r];
+      reinterpret_cast<f32x4*>(out)[i] = acc * scale;
+    }
+  }
+  publish_when_last(fl, S, 1, slot, nranks, rank, epoch);   // (after a timeout too: the peers must not hang on this rank)
+}
+
+__global__ __launch_bounds__(256) void xgmi_ag_sync_kernel(XgmiPeers peers, XgmiFlags fl, int S, int slot, unsigned epoch,
+                                                           int nranks, int rank, long long off, long long chunk,
+                                                           long long n) {
+  __shared__ int ok_s;
+  if (threadIdx.x == 0) {
+    ok_s = wait_flags(fl.f[rank], S, 1, slot, nranks, (unsigned)rank, epoch, 2) ? 1 : 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  if (ok_s) {
+    float* mine = peers.p[rank] + off;
+    for (int j = 0; j < nranks; ++j) {
+      if (j == rank) continue;
+      const long long c0 = (long long)j * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;
+      if (c1 <= c0) continue;
+      const long long n4 = (c1 - c0) >> 2;
+      const f32x4* src = reinterpret_cast<const f32x4*>(peers.p[j] + off + c0);
+      f32x4* dst = reinterpret_cast<f32x4*>(mine + c0);
+      for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = __builtin_nontemporal_load(src + i);
+    }
+  }
+  publish_when_last(fl, S, 2, slot, nranks, rank, epoch);
+}
+
+// one block: every listed slot's region has been read by every peer (their all-gathers are done)
+__global__ __launch_bounds__(64) void xgmi_wait_gathered_kernel(XgmiFlags fl, int S, int rank, int nranks, const int* slots,
+                                                                const unsigned* epochs, int nslots) {
+  if (threadIdx.x == 0)
+    for (int k = 0; k < nslots; ++k)
+      if (!wait_flags(fl.f[rank], S, 2, slots[k], nranks, (unsigned)rank, epochs[k], 3)) break;
+}
+
+int fill_flags(const int64_t* flag_ptrs, int nranks, XgmiFlags& f) {
+  for (int r = 0; r < XGMI_MAX_RANKS; ++r) f.f[r] = r < nranks ? reinterpret_cast<unsigned*>(flag_ptrs[r]) : nullptr;
+  for (int r = 0; r < nranks; ++r)
+    if (!f.f[r] || (reinterpret_cast<uintptr_t>(f.f[r]) & 3)) return 1;
+  return 0;
+}
+
+int xgmi_blocks(long long n4) {
+  static int cap = 0;
+  if (cap == 0) {
+    const char* e = getenv("NVIT_XGMI_BLOCKS");   // blocks per collective kernel: few enough to leave the CUs to backward
+    cap = e ? atoi(e) : 32;
+    if (cap < 1) cap = 1;
+    if (cap > 2048) cap = 2048;
+  }
+  int b = cdiv(n4, 256);
+  return b < 1 ? 1 : (b > cap ? cap : b);
+}
+
+}  // namespace
+
+extern "C" int64_t nvit_xgmi_flag_bytes(int nslots) {
+  if (nslots < 1 || nslots > XGMI_MAX_SLOTS) return 0;
+  const int64_t words = (int64_t)3 * nslots * XGMI_MAX_RANKS + nslots + 1;
+  return (words * 4 + 255) / 256 * 256;
+}
+
+// Uncached (cross-device coherent) device memory for the flag block, zero-filled, with its IPC handle (64 bytes).
+extern "C" int nvit_xgmi_flags_alloc(int nslots, void** dev_ptr, void* ipc_handle_out) {
+  const int64_t bytes = nvit_xgmi_flag_bytes(nslots);
+  NVIT_REQUIRE(bytes > 0 && dev_ptr && ipc_handle_out, "xgmi_flags_alloc: 1..%d slots", XGMI_MAX_SLOTS);
+  void* p = nullptr;
+  hipError_t e = hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) NVIT_FAIL((int)e, "xgmi_flags_alloc: hipExtMallocWithFlags(uncached): %s", hipGetErrorString(e));
+  e = hipMemset(p, 0, (size_t)bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(ipc_handle_out), p);
+  if (e != hipSuccess) {
+    (void)hipFree(p);
+    NVIT_FAIL((int)e, "xgmi_flags_alloc: %s", hipGetErrorString(e));
+  }
+  *dev_ptr = p;
+  return NVIT_OK;
+}
+
+extern "C" int nvit_xgmi_flags_open(const void* ipc_handle, void** dev_ptr) {
+  NVIT_REQUIRE(ipc_handle && dev_ptr, "xgmi_flags_open: null argument");
+  hipIpcMemHandle_t h;
+  memcpy(&h, ipc_handle, sizeof(h));
+  hipError_t e = hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) NVIT_FAIL((int)e, "xgmi_flags_open: hipIpcOpenMemHandle: %s", hipGetErrorString(e));
+  return NVIT_OK;
+}
+
+extern "C" int nvit_xgmi_flags_close(void* dev_ptr) {
+  hipError_t e = hipIpcCloseMemHandle(dev_ptr);
+  if (e != hipSuccess) NVIT_FAIL((int)e, "xgmi_flags_close: %s", hipGetErrorString(e));
+  return NVIT_OK;
+}
+
+extern "C" int nvit_xgmi_flags_free(void* dev_ptr) {
+  hipError_t e = hipFree(dev_ptr);
+  if (e != hipSuccess) NVIT_FAIL((int)e, "xgmi_flags_free: %s", hipGetErrorString(e));
+  return NVIT_OK;
+}
+
+// error word of this rank's own flag block (0 = no wait has timed out); synchronises the stream first
+extern "C" int nvit_xgmi_flags_error(const void* own_flags, int nslots, unsigned* out, void* stream) {
+  NVIT_REQUIRE(own_flags && out && nvit_xgmi_flag_bytes(nslots) > 0, "xgmi_flags_error: bad arguments");
+  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  if (e == hipSuccess)
+    e = hipMemcpy(out, (const unsigned*)own_flags + (size_t)3 * nslots * XGMI_MAX_RANKS + nslots, 4, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) NVIT_FAIL((int)e, "xgmi_flags_error: %s", hipGetErrorString(e));
+  return NVIT_OK;
+}
+
+// Region [off, off + n) of the symmetric buffers (elements; off and n multiples of 4), slot `slot`, call number `epoch`
+// (>= 1, the same on every rank, increasing per slot).  chunk = nvit_xgmi_chunk(n, nranks).
+extern "C" int nvit_xgmi_reduce_scatter_sync(const int64_t* peer_ptrs, const int64_t* flag_ptrs, int nranks, int rank,
+                                             int nslots, int slot, unsigned epoch, int64_t off, int64_t n, float scale,
+                                             void* stream) {
+  NVIT_REQUIRE(peer_ptrs && flag_ptrs && nranks >= 1 && nranks <= XGMI_MAX_RANKS && rank >= 0 && rank < nranks && n > 0 &&
+                   n % 4 == 0 && off >= 0 && off % 4 == 0 && nslots >= 1 && nslots <= XGMI_MAX_SLOTS && slot >= 0 &&
+                   slot < nslots && epoch != 0,
+               "xgmi_reduce_scatter_sync: bad arguments");
+  XgmiPeers p;
+  XgmiFlags f;
+  NVIT_REQUIRE(fill_peers(peer_ptrs, nranks, p) == 0 && fill_flags(flag_ptrs, nranks, f) == 0,
+               "xgmi_reduce_scatter_sync: peer / flag pointers must be non-null and aligned");
+  const int64_t chunk = nvit_xgmi_chunk(n, nranks);
+  int64_t c0 = (int64_t)rank * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;
+  if (c1 < c0) c1 = c0;   // (a rank without a chunk still takes part in the flag protocol)
+  hipLaunchKernelGGL(xgmi_rs_sync_kernel, dim3(xgmi_blocks((c1 - c0) / 4)), dim3(256), 0, (hipStream_t)stream, p, f, nslots,
+                     slot, epoch, nranks, rank, (long long)off, (long long)c0, (long long)c1, scale);
+  NVIT_CHECK_LAUNCH("xgmi_reduce_scatter_sync");
+  return NVIT_OK;
+}
+
+extern "C" int nvit_xgmi_all_gather_sync(const int64_t* peer_ptrs, const int64_t* flag_ptrs, int nranks, int rank, int nslots,
+                                         int slot, unsigned epoch, int64_t off, int64_t n, void* stream) {
+  NVIT_REQUIRE(peer_ptrs && flag_ptrs && nranks >= 1 && nranks <= XGMI_MAX_RANKS && rank >= 0 && rank < nranks && n > 0 &&
+                   n % 4 == 0 && off >= 0 && off % 4 == 0 && nslots >= 1 && nslots <= XGMI_MAX_SLOTS && slot >= 0 &&
+                   slot < nslots && epoch != 0,
+               "xgmi_all_gather_sync: bad arguments");
+  XgmiPeers p;
+  XgmiFlags f;
+  NVIT_REQUIRE(fill_peers(peer_ptrs, nranks, p) == 0 && fill_flags(flag_ptrs, nranks, f) == 0,
+               "xgmi_all_gather_sync: peer / flag pointers must be non-null and aligned");
+  const int64_t chunk = nvit_xgmi_chunk(n, nranks);
+  hipLaunchKernelGGL(xgmi_ag_sync_kernel, dim3(xgmi_blocks(chunk / 4)), dim3(256), 0, (hipStream_t)stream, p, f, nslots, slot,
+                     epoch, nranks, rank, (long long)off, (long long)chunk, (long long)n);
+  NVIT_CHECK_LAUNCH("xgmi_all_gather_sync");
+  return NVIT_OK;
+}
+
+// slots / epochs: DEVICE arrays of nwait entries (which slots, and the epoch each must have reached)
+extern "C" int nvit_xgmi_wait_gathered(const int64_t* flag_ptrs, int nranks, int rank, int nslots, const int* slots,
+                                       const unsigned* epochs, int nwait, void* stream) {
+  NVIT_REQUIRE(flag_ptrs && nranks >= 1 && nranks <= XGMI_MAX_RANKS && rank >= 0 && rank < nranks && nslots >= 1 &&
+                   nslots <= XGMI_MAX_SLOTS && slots && epochs && nwait >= 1 && nwait <= XGMI_MAX_SLOTS,
+               "xgmi_wait_gathered: bad arguments");
+  XgmiFlags f;
+  NVIT_REQUIRE(fill_flags(flag_ptrs, nranks, f) == 0, "xgmi_wait_gathered: flag pointers must be non-null and aligned");
+  hipLaunchKernelGGL(xgmi_wait_gathered_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, f, nslots, rank, nranks, slots,
+                     epochs, nwait);
+  NVIT_CHECK_LAUNCH("xgmi_wait_gathered");
   return NVIT_OK;
 }

@@ -15,6 +15,8 @@ Design (MI355X: 8 GPUs, fully connected xGMI mesh, 7 links/GPU):
   * parameters that never receive a gradient (rmsnorm_* weights, reconstruction head without the
     Kohonen loss, SURVEY.md §9.1-Q6) are detected on the first backward and left out of the buckets;
   * `no_sync()` suppresses communication for gradient-accumulation micro-steps;
+  * `collective="xgmi"`: the same buckets reduced by the hand-written direct collective, per bucket on a side stream,
+    phases separated by device-side flags (no host barrier); call `close()` before tearing the process group down;
   * after the collective, `p.grad` is re-pointed at its slice of the reduced flat bucket (no copy back);
   * gradients are PRODUCED in the buckets where possible ("gradient as bucket view"): the model's backward asks
     `module._grad_sink` for the destination of a weight gradient and the weight-gradient GEMM writes straight into
@@ -66,13 +68,14 @@ class DataParallel(nn.Module):
     def __init__(self, module: nn.Module, process_group=None, bucket_cap_mb: float = 40.0,
                  broadcast_parameters: bool = True, collective: str = "rccl") -> None:
         """collective: "rccl" (default) = bucketed torch.distributed all-reduce overlapped with backward;
-        "xgmi" = the hand-written direct reduce-scatter / all-gather over IPC-mapped buffers (nvit_amd/xgmi.py, SURVEY §8f
-        F3): all buckets live in one symmetric buffer that is reduced once at the end of backward (no overlap yet)."""
+        "xgmi" (EXPERIMENTAL: verified with ranks sharing one device only, never timed on links) = the hand-written direct
+        reduce-scatter / all-gather over IPC-mapped buffers with device-side phase flags (nvit_amd/xgmi.py):
+        all buckets live in one symmetric buffer, each bucket is reduced on a side stream as soon as it is complete."""
         super().__init__()
         if not dist.is_initialized():
             raise RuntimeError("DataParallel needs an initialised torch.distributed process group")
         if collective not in ("rccl", "xgmi"):
-            raise ValueError("collective must be 'rccl' or 'xgmi'")
+            raise ValueError("collective must be 'rccl' or 'xgmi' (xgmi: experimental direct collective)")
         self.module = module
         self.collective = collective
         self._xg = None
@@ -144,7 +147,17 @@ class DataParallel(nn.Module):
             self._launch(b)
 
     def _launch(self, b: _Bucket) -> None:
-        if self._xg is not None:   # direct xGMI collective: the whole symmetric buffer goes at the end of backward
+        if self._xg is not None:
+            # direct xGMI collective, per bucket, on the communication stream: it starts when the kernels that produced
+            # this bucket's gradients (already enqueued on the current stream) are done, waits for the peers ON THE DEVICE,
+            # and runs under the rest of backward (nvit_amd/xgmi.py; the 1/N is folded into the reduce)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._comm.wait_event(ev)
+            e = self._xg.begin(b.slot)
+            st = self._comm.cuda_stream
+            self._xg.reduce_scatter_(b.slot, e, 1.0 / self.world, b.off, b.numel, stream=st)
+            self._xg.all_gather_(b.slot, e, b.off, b.numel, stream=st)
             b.handle = _Done()
             return
         b.handle = self._mean_all_reduce(b.flat, async_op=True)
@@ -211,13 +224,18 @@ class DataParallel(nn.Module):
         if cur:
             buckets.append(_Bucket(cur))
         if self.collective == "xgmi" and buckets:
-            from .xgmi import XgmiAllReduce
-            self._xg = XgmiAllReduce(sum(b.numel for b in buckets), buckets[0].params[0].device, self.group)
+            from .xgmi import MAX_SLOTS, XgmiAllReduce
+            if len(buckets) > MAX_SLOTS:
+                raise RuntimeError(f"collective='xgmi': {len(buckets)} buckets, at most {MAX_SLOTS} (raise bucket_cap_mb)")
+            self._xg = XgmiAllReduce(sum(b.numel for b in buckets), buckets[0].params[0].device, self.group,
+                                     slots=len(buckets))
+            self._comm = torch.cuda.Stream()
         off = 0
-        for b in buckets:
+        for k, b in enumerate(buckets):
             ref = b.params[0]
             if self._xg is not None:   # bucket = slice of the symmetric buffer every rank maps (numel is a multiple of 4)
                 b.flat = self._xg.buffer[off: off + b.numel]
+                b.slot, b.off = k, off
                 off += b.numel
             else:
                 b.flat = torch.zeros(b.numel, device=ref.device, dtype=ref.dtype)
@@ -251,7 +269,12 @@ class DataParallel(nn.Module):
                         b.slice_of(i).zero_()
                 self._launch(b)
         if self._xg is not None:
-            self._xg.all_reduce_(1.0 / self.world)
+            # the optimizer (current stream) runs after the last all-gather, and the next backward may rewrite the
+            # buckets only when every peer has finished reading them: both are device-side waits, no host round trip
+            done = torch.cuda.Event()
+            done.record(self._comm)
+            torch.cuda.current_stream().wait_event(done)
+            self._xg.wait_gathered([b.slot for b in self._buckets])
         for p in self._late:
             self._mean_all_reduce(p.grad, async_op=False)
         self._late = []
@@ -260,6 +283,13 @@ class DataParallel(nn.Module):
                 b.handle.wait()
                 b.handle = None
             b.pending = len(b.params)
+
+    def close(self) -> None:
+        """Release the direct collective's peer mappings (every rank; no-op for RCCL)."""
+        if self._xg is not None:
+            self._xg.check_error()
+            self._xg.close()
+            self._xg = None
 
     def finish(self) -> None:
         """Kept for explicit callers (bench.py): the end-of-backward callback already waited."""

@@ -1,6 +1,9 @@
 """the hand-written reduce-scatter / all-gather kernels behind nvit_amd.xgmi.XgmiAllReduce, exercised by
-2 and 4 fresh processes that share the box's one MI355X (IPC-mapped symmetric buffers; on a multi-GPU node the same peer
-reads travel over xGMI).  Sums must equal the rank-ordered reference and be bit-identical on every rank."""
+2 and 4 fresh processes that share the box's one MI355X (IPC-mapped symmetric buffers and uncached flag blocks; on a
+multi-GPU node the same peer reads and flag stores travel over xGMI).  Phases are separated by device-side flags only
+(no host barrier inside a collective): ranks arrive skewed, and in the multi-slot case every reduce-scatter of four
+regions is enqueued before any all-gather, on two streams.  Sums must equal the rank-ordered reference and be
+bit-identical on every rank."""
 import json
 import os
 import socket
@@ -46,7 +49,8 @@ def test_xgmi_all_reduce_shared_device(world, tmp_path):
         raise AssertionError("\n".join(f"--- rank {i} rc={p.returncode}\n{o[-1500:]}" for i, (p, o) in enumerate(zip(procs, logs))))
     for out in outs:
         r = json.load(open(out))
-        assert len(r["cases"]) == 4
+        assert len(r["cases"]) == 4 and r["shared_device"]
+        assert r["multi_slot"]["max_err"] < 1e-5 and r["multi_slot"]["bit_identical_across_ranks"], r["multi_slot"]
         for c in r["cases"]:
             assert c["max_err"] < 1e-5, c            # (the reference sums in the same order; fp32 rounding of the 1/world scale)
             assert c["bit_identical_across_ranks"] and c["padding_zero"], c

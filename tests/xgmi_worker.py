@@ -3,6 +3,7 @@ usage: python tests/xgmi_worker.py <out.json>   (RANK / WORLD_SIZE / MASTER_ADDR
 import json
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,7 +27,8 @@ def main():
     dist.init_process_group("gloo", init_method="env://")
     res = {"rank": rank, "world": world, "cases": []}
     sizes = (4, 1000, 1 << 20, 9437185)     # incl. sizes that are not multiples of 4 * world, and one nGPT block + 1
-    ar = XgmiAllReduce(max(sizes), dev)     # ONE symmetric buffer (one IPC export per process); prefixes of it are reduced
+    ar = XgmiAllReduce(max(sizes), dev, slots=4)   # ONE symmetric buffer (one IPC export per process); prefixes of it are reduced
+    res["shared_device"] = bool(ar.shared_device)
     for n in sizes:
         n4 = (n + 3) // 4 * 4
         worst, equal = 0.0, True
@@ -34,7 +36,9 @@ def main():
             ar.buffer.zero_()
             ar.buffer[:n] = fill(rank, n, step, dev)
             ar.buffer[n4:] = 7.0                                  # outside the reduced prefix: must stay untouched
-            got = ar.all_reduce_(1.0 / world, numel=n)[:n].clone()
+            if step == 1:
+                time.sleep(0.05 * rank)                           # ranks arrive at different times: the flags must absorb it
+            got = ar.all_reduce_(1.0 / world, numel=n)[:n].clone()   # (no host barrier inside: device-side flags only)
             want = sum(fill(r, n, step, dev) for r in range(world)) / world   # same order 0..world-1 as the kernel
             worst = max(worst, (got - want).abs().max().item())
             both = [torch.empty(n) for _ in range(world)]
@@ -43,6 +47,37 @@ def main():
             pad_ok = bool((ar.buffer[n:n4] == 0).all().item()) and bool((ar.buffer[n4:] == 7.0).all().item())
         res["cases"].append({"n": n, "chunk": int(ar.chunk), "max_err": worst, "bit_identical_across_ranks": equal,
                              "padding_zero": pad_ok})
+    # several regions in flight: four "buckets" (slots) of different sizes; ALL reduce-scatters are enqueued before ANY
+    # all-gather, on two streams, with skewed ranks and no host synchronisation in between - a bucket's reduce-scatter
+    # starts (and finishes) while earlier buckets' all-gathers have not even been enqueued
+    regions = [(0, 262144), (262144, 1000), (263144, 4), (263148, 3000000)]   # (offset, numel), offsets multiples of 4
+    s2 = torch.cuda.Stream()
+    ok_multi, worst = True, 0.0
+    for step in range(3):
+        ar.buffer.zero_()
+        for k, (off, n) in enumerate(regions):
+            ar.buffer[off:off + n] = fill(rank, n, 10 * step + k, dev)
+        torch.cuda.synchronize()
+        time.sleep(0.03 * ((rank + step) % world))
+        eps = [ar.begin(k) for k in range(len(regions))]
+        cur = torch.cuda.current_stream()
+        for k, (off, n) in enumerate(regions):
+            st = (s2 if k % 2 else cur).cuda_stream
+            ar.reduce_scatter_(k, eps[k], 1.0 / world, off, n, stream=st)
+        for k, (off, n) in reversed(list(enumerate(regions))):
+            st = (s2 if k % 2 else cur).cuda_stream
+            ar.all_gather_(k, eps[k], off, n, stream=st)
+        cur.wait_stream(s2)
+        ar.wait_gathered(range(len(regions)))
+        for k, (off, n) in enumerate(regions):
+            got = ar.buffer[off:off + n].clone()
+            want = sum(fill(r, n, 10 * step + k, dev) for r in range(world)) / world
+            worst = max(worst, (got - want).abs().max().item())
+            both = [torch.empty(n) for _ in range(world)]
+            dist.all_gather(both, got.cpu())
+            ok_multi = ok_multi and all(torch.equal(both[0], b) for b in both[1:])
+    res["multi_slot"] = {"max_err": worst, "bit_identical_across_ranks": ok_multi}
+    ar.check_error()
     ar.close()
     json.dump(res, open(out_path, "w"))
     dist.barrier()
