@@ -169,10 +169,13 @@ int nvit_gemm_tn(int dt, const void* A, int lda, const void* B, int ldb, float* 
 int nvit_lerp_fwd(int dt, const float* h, const void* y, int y_dt, const float* alpha, float c_a,
                   const float* skip_x, const float* skip, float* out, void* out_lo, int M, int C, void* stream);
 /* nvit_lerp_bwd: given dout, recomputes the forward and writes dh (fp32; += if accum_dh), dy (fp32
- * and/or type-dt copy, either may be NULL), dskip_x (fp32, written, only if skip_x), and per-block
- * partial sums part_dlam [nblk, C] (d/d|alpha*c_a|) and part_dskip [nblk] (if skip_x).
- * nblk = number of workgroups the caller sizes the partial buffers for (<= 4096). */
-int nvit_lerp_bwd(int dt, const float* dout, const float* h, const void* y, int y_dt, const float* alpha,
+ * and/or type-dt copy, either may be NULL), dskip_x (fp32, written, only if skip_x), and per-WAVE
+ * partial sums part_dlam [4*nblk, C] (d/d|alpha*c_a|) and part_dskip [4*nblk] (if skip_x).
+ * nblk = number of 4-wave workgroups the caller sizes the partial buffers for (<= 4096).
+ * dout_add (bf16 [M,C] or NULL): the incoming gradient is dout + dout_add - lets the data-gradient GEMM that produced
+ * dout_add store bf16 once instead of read-modify-writing the fp32 dout (the reference's autocast nn.Linear hands its
+ * input gradient back in bf16 as well). */
+int nvit_lerp_bwd(int dt, const float* dout, const void* dout_add, const float* h, const void* y, int y_dt, const float* alpha,
                   float c_a, const float* skip_x, const float* skip, float* dh, int accum_dh, float* dy,
                   void* dy_lo, float* dskip_x, float* part_dlam, float* part_dskip, int nblk, int M, int C,
                   void* stream);

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnvit_hip.so")
+# (NVIT_LIB: experiments with an alternative build of the same sources, e.g. tools/overlap_probe.py; never set in product use)
+LIB_PATH = os.environ.get("NVIT_LIB") or os.path.join(_HERE, "libnvit_hip.so")
 
 F32, BF16, BF16_F32IN = 0, 1, 3
 KID_NAMES = ["gemm_nt", "gemm_tn", "attn_fwd", "attn_bwd", "rowops", "renorm", "shadow", "patchify", "misc", "gemm_f32",
@@ -42,7 +43,7 @@ SIGNATURES = {
     "nvit_gemm_nt_qknorm": [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "nvit_gemm_tn": [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i64, _i, _i, _vp],
     "nvit_lerp_fwd": [_i, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
-    "nvit_lerp_bwd": [_i, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "nvit_lerp_bwd": [_i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "nvit_norm_skip_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "nvit_norm_skip_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "nvit_qknorm_fwd": [_i, _vp, _i, _vp, _i, _vp, _i, _vp, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

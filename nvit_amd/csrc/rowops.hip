@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void lerp_fwd_kernel(LerpFwdArgs a) {
 // ------------------------------------------------------------------------------ LERP backward
 struct LerpBwdArgs {
   const float* dout;
+  const bf16* dout_add;   // optional second addend of the incoming gradient (a data-gradient GEMM's bf16 output), or NULL
   const float* h;
   const void* y;
   const float* alpha;
@@ -108,9 +109,26 @@ struct LerpBwdArgs {
   int M, C;
 };
 
-template <int NV, typename TY, typename TL>
-__global__ __launch_bounds__(256) void lerp_bwd_kernel(LerpBwdArgs a) {
-  __shared__ float red[ROW_WAVES][NV * 256 + 4];
+// ADD: the incoming gradient has a second, bf16 addend (a.dout_add).  A template switch, not a run-time test: with the test
+// inside the row loop hipcc waits for the addend right where it is loaded, before the remaining loads of the row have
+// been issued - a second memory round trip per row (+137 us per Base block, measured).
+//
+// Register-lean form: per row only the two unit vectors a, b and the running gradient g stay in registers (plus the
+// per-column step sizes and their gradient sums); the LERP output o = (a + lam*(b - a)) * rsr is recomputed where it is
+// needed (three flops per element) and da / db are formed at the store.  No LDS: every wave writes its own row of
+// column partials (part_dlam [4*nblk, C], part_dskip [4*nblk]).  At C = 768 this is 104 registers instead of 160
+// (4 waves per SIMD instead of 3) - small enough to be co-resident with two waves of the 193-register weight-gradient
+// GEMM on the same SIMD.
+template <int NV>
+__device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+}
+
+#ifndef NVIT_LERP_BWD_WAVES
+#define NVIT_LERP_BWD_WAVES 1
+#endif
+template <int NV, typename TY, typename TL, bool ADD>
+__global__ __launch_bounds__(256, NVIT_LERP_BWD_WAVES) void lerp_bwd_kernel(LerpBwdArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   RowVec<NV> lam, dlam;
   row_load<NV, float>(lam, a.alpha, a.C, lane);
@@ -123,84 +141,93 @@ __global__ __launch_bounds__(256) void lerp_bwd_kernel(LerpBwdArgs a) {
   const float skip = a.skip_x ? a.skip[0] : 0.f;
   float dskip_acc = 0.f;
   for (int m = blockIdx.x * ROW_WAVES + wid; m < a.M; m += gridDim.x * ROW_WAVES) {
-    RowVec<NV> x, y, av, bv, o, g, t, old;
-    row_load<NV, float>(x, a.h + (size_t)m * a.C, a.C, lane);
-    row_load<NV, TY>(y, reinterpret_cast<const TY*>(a.y) + (size_t)m * a.C, a.C, lane);
-    row_load<NV, float>(g, a.dout + (size_t)m * a.C, a.C, lane);
+    RowVec<NV> av, bv, g, t, old, ga;   // av: h then a = nrm(h); bv: y then b = nrm(y); g: incoming gradient, then d(lerp out), then dr
+    const size_t ro = (size_t)m * a.C;
     // every load of the row goes out before the first reduction: one memory round trip per row, not two or three
-    float* const dhp = a.dh + (size_t)m * a.C;
-    if (a.skip_x) row_load<NV, float>(t, a.skip_x + (size_t)m * a.C, a.C, lane);
-    if (a.accum_dh) row_load<NV, float>(old, dhp, a.C, lane);
-    const float rsx = 1.0f / sqrtf(row_dot<NV>(x, x));
-    const float rsy = 1.0f / sqrtf(row_dot<NV>(y, y));
+    row_load<NV, float>(av, a.h + ro, a.C, lane);
+    row_load<NV, TY>(bv, reinterpret_cast<const TY*>(a.y) + ro, a.C, lane);
+    row_load<NV, float>(g, a.dout + ro, a.C, lane);
+    if constexpr (ADD) row_load<NV, bf16>(ga, a.dout_add + ro, a.C, lane);
+    if (a.skip_x) row_load<NV, float>(t, a.skip_x + ro, a.C, lane);
+    if (a.accum_dh) row_load<NV, float>(old, a.dh + ro, a.C, lane);
+    if constexpr (ADD) {   // incoming gradient = dout + dout_add: the GEMM that produced dout_add need not read-modify-write dout
+#pragma unroll
+      for (int i = 0; i < NV; ++i) g.v[i] += ga.v[i];
+    }
+    const float rsx = 1.0f / sqrtf(row_dot<NV>(av, av));
+    const float rsy = 1.0f / sqrtf(row_dot<NV>(bv, bv));
+    float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      av.v[i] = x.v[i] * rsx;
-      bv.v[i] = y.v[i] * rsy;
-      o.v[i] = av.v[i] + lam.v[i] * (bv.v[i] - av.v[i]);
+      av.v[i] = av.v[i] * rsx;
+      bv.v[i] = bv.v[i] * rsy;
+      const f32x4 ou = av.v[i] + lam.v[i] * (bv.v[i] - av.v[i]);
+      ss += dot4<NV>(ou, ou);
     }
-    const float rsr = 1.0f / sqrtf(row_dot<NV>(o, o));
-#pragma unroll
-    for (int i = 0; i < NV; ++i) o.v[i] = o.v[i] * rsr;  // o = h2 = lerp output (unit norm)
+    const float rsr = 1.0f / sqrtf(wave_sum(ss));
+#define NVIT_LERP_O(i_) ((av.v[i_] + lam.v[i_] * (bv.v[i_] - av.v[i_])) * rsr)   /* o = lerp output (unit norm), recomputed */
     if (a.skip_x) {
       // t = o*skip + xs ; out = t/|t| ; dt = (g - out<out,g>)/|t| ; do = skip*dt ; dxs = dt ; dskip += <dt,o>
+      float st = 0.f;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) t.v[i] = o.v[i] * skip + t.v[i];
-      const float rst = 1.0f / sqrtf(row_dot<NV>(t, t));
+      for (int i = 0; i < NV; ++i) {
+        t.v[i] = NVIT_LERP_O(i) * skip + t.v[i];
+        st += dot4<NV>(t.v[i], t.v[i]);
+      }
+      const float rst = 1.0f / sqrtf(wave_sum(st));
+      float tg = 0.f;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) t.v[i] = t.v[i] * rst;
-      const float tg = row_dot<NV>(t, g);
+      for (int i = 0; i < NV; ++i) {
+        t.v[i] = t.v[i] * rst;
+        tg += dot4<NV>(t.v[i], g.v[i]);
+      }
+      tg = wave_sum(tg);
+      float dso = 0.f;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) g.v[i] = (g.v[i] - t.v[i] * tg) * rst;  // g = dt
-      row_store<NV, float>(g, a.dskip_x + (size_t)m * a.C, a.C, lane);
-      dskip_acc += row_dot<NV>(g, o);
+      for (int i = 0; i < NV; ++i) {
+        g.v[i] = (g.v[i] - t.v[i] * tg) * rst;   // g = dt
+        dso += dot4<NV>(g.v[i], NVIT_LERP_O(i));
+      }
+      row_store<NV, float>(g, a.dskip_x + ro, a.C, lane);
+      dskip_acc += wave_sum(dso);
 #pragma unroll
-      for (int i = 0; i < NV; ++i) g.v[i] = g.v[i] * skip;  // g = d(lerp output)
+      for (int i = 0; i < NV; ++i) g.v[i] = g.v[i] * skip;   // g = d(lerp output)
     }
     // dr = (g - o<o,g>) * rsr
-    const float og = row_dot<NV>(o, g);
-    RowVec<NV> da, db;
+    float og = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) og += dot4<NV>(NVIT_LERP_O(i), g.v[i]);
+    og = wave_sum(og);
+    float ada = 0.f, bdb = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const f32x4 dr = (g.v[i] - o.v[i] * og) * rsr;
-      dlam.v[i] += dr * (bv.v[i] - av.v[i]);
-      da.v[i] = dr - lam.v[i] * dr;
-      db.v[i] = lam.v[i] * dr;
+      g.v[i] = (g.v[i] - NVIT_LERP_O(i) * og) * rsr;   // g = dr
+      dlam.v[i] += g.v[i] * (bv.v[i] - av.v[i]);
+      const f32x4 db = lam.v[i] * g.v[i];
+      ada += dot4<NV>(av.v[i], g.v[i] - db);
+      bdb += dot4<NV>(bv.v[i], db);
     }
-    const float ada = row_dot<NV>(av, da);
-    const float bdb = row_dot<NV>(bv, db);
+#undef NVIT_LERP_O
+    ada = wave_sum(ada);
+    bdb = wave_sum(bdb);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      da.v[i] = (da.v[i] - av.v[i] * ada) * rsx;  // dh
-      db.v[i] = (db.v[i] - bv.v[i] * bdb) * rsy;  // dy
+      const int c = (i * 64 + lane) * 4;
+      const f32x4 db = lam.v[i] * g.v[i];
+      f32x4 dh = ((g.v[i] - db) - av.v[i] * ada) * rsx;
+      const f32x4 dy = (db - bv.v[i] * bdb) * rsy;
+      if (a.accum_dh) dh += old.v[i];
+      if (c < a.C) {
+        store4<float>(a.dh + ro + c, dh);
+        if (a.dy) store4<float>(a.dy + ro + c, dy);
+        if (a.dy_lo) store4<TL>(reinterpret_cast<TL*>(a.dy_lo) + ro + c, dy);
+      }
     }
-    if (a.accum_dh) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) da.v[i] += old.v[i];
-    }
-    row_store<NV, float>(da, dhp, a.C, lane);
-    if (a.dy) row_store<NV, float>(db, a.dy + (size_t)m * a.C, a.C, lane);
-    if (a.dy_lo) row_store<NV, TL>(db, reinterpret_cast<TL*>(a.dy_lo) + (size_t)m * a.C, a.C, lane);
   }
-  // reduce the 4 waves' column partials through LDS, fixed order
-#pragma unroll
-  for (int i = 0; i < NV; ++i)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) red[wid][(i * 64 + lane) * 4 + e] = dlam.v[i][e];
-  if (lane == 0) red[wid][NV * 256] = dskip_acc;
-  __syncthreads();
-  for (int c = threadIdx.x; c < a.C; c += 256) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < ROW_WAVES; ++w) s += red[w][c];
-    a.part_dlam[(size_t)blockIdx.x * a.C + c] = s;
-  }
-  if (a.skip_x && threadIdx.x == 0) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < ROW_WAVES; ++w) s += red[w][NV * 256];
-    a.part_dskip[blockIdx.x] = s;
-  }
+  // column partials: one row per wave (fixed layout, reduced in fixed order by nvit_colsum_reduce)
+  const size_t prow = (size_t)blockIdx.x * ROW_WAVES + wid;
+  row_store<NV, float>(dlam, a.part_dlam + prow * a.C, a.C, lane);
+  if (a.skip_x && lane == 0) a.part_dskip[prow] = dskip_acc;
 }
 
 // ------------------------------------------------------------------------------ standalone norm_skip
@@ -656,26 +683,37 @@ extern "C" int nvit_lerp_fwd(int dt, const float* h, const void* y, int y_dt, co
   return NVIT_OK;
 }
 
-extern "C" int nvit_lerp_bwd(int dt, const float* dout, const float* h, const void* y, int y_dt, const float* alpha,
+extern "C" int nvit_lerp_bwd(int dt, const float* dout, const void* dout_add, const float* h, const void* y, int y_dt, const float* alpha,
                              float c_a, const float* skip_x, const float* skip, float* dh, int accum_dh, float* dy,
                              void* dy_lo, float* dskip_x, float* part_dlam, float* part_dskip, int nblk, int M,
                              int C, void* stream) {
   NVIT_REQUIRE(C % 4 == 0 && C <= 2048 && M > 0, "lerp_bwd: C=%d must be a multiple of 4 and <= 2048", C);
   NVIT_REQUIRE(nblk > 0 && nblk <= 4096, "lerp_bwd: nblk out of range");
   NVIT_REQUIRE(!skip_x || (skip && dskip_x && part_dskip), "lerp_bwd: skip buffers missing");
-  LerpBwdArgs a{dout, h, y, alpha, c_a, skip_x, skip, dh, accum_dh, dy, dy_lo, dskip_x, part_dlam, part_dskip, M, C};
+  LerpBwdArgs a{dout, (const bf16*)dout_add, h, y, alpha, c_a, skip_x, skip, dh, accum_dh, dy, dy_lo, dskip_x, part_dlam, part_dskip, M, C};
   hipStream_t s = (hipStream_t)stream;
-  ProfScope ps(NVIT_KID_ROWOPS, 0.0, (double)M * C * 24.0, s);
+  // algorithmic bytes: dout, h read, y read (2 or 4 B), dh written, dy_lo written (+ skip_x read, dskip_x written; + dout_add)
+  const double lb_bytes = (double)M * C * (4.0 + 4.0 + (y_dt == NVIT_F32 ? 4.0 : 2.0) + 4.0 + (dy ? 4.0 : 0.0) + (dy_lo ? (dt == NVIT_F32 ? 4.0 : 2.0) : 0.0) +
+                                           (skip_x ? 8.0 : 0.0) + (accum_dh ? 4.0 : 0.0) + (dout_add ? 2.0 : 0.0));
+  ProfScope ps(NVIT_KID_ROWOPS, 0.0, lb_bytes, s);
+#define NVIT_LERP_BWD_LAUNCH(TY_, TL_)                                                                       \
+  {                                                                                                          \
+    if (dout_add)                                                                                            \
+      hipLaunchKernelGGL((lerp_bwd_kernel<NV, TY_, TL_, true>), dim3(nblk), dim3(256), 0, s, a);             \
+    else                                                                                                     \
+      hipLaunchKernelGGL((lerp_bwd_kernel<NV, TY_, TL_, false>), dim3(nblk), dim3(256), 0, s, a);            \
+  }
   DISPATCH_NV(C, {
     if (y_dt == NVIT_F32 && dt == NVIT_F32)
-      hipLaunchKernelGGL((lerp_bwd_kernel<NV, float, float>), dim3(nblk), dim3(256), 0, s, a);
+      NVIT_LERP_BWD_LAUNCH(float, float)
     else if (y_dt == NVIT_F32)
-      hipLaunchKernelGGL((lerp_bwd_kernel<NV, float, bf16>), dim3(nblk), dim3(256), 0, s, a);
+      NVIT_LERP_BWD_LAUNCH(float, bf16)
     else if (dt == NVIT_F32)
-      hipLaunchKernelGGL((lerp_bwd_kernel<NV, bf16, float>), dim3(nblk), dim3(256), 0, s, a);
+      NVIT_LERP_BWD_LAUNCH(bf16, float)
     else
-      hipLaunchKernelGGL((lerp_bwd_kernel<NV, bf16, bf16>), dim3(nblk), dim3(256), 0, s, a);
+      NVIT_LERP_BWD_LAUNCH(bf16, bf16)
   });
+#undef NVIT_LERP_BWD_LAUNCH
   NVIT_CHECK_LAUNCH("lerp_bwd");
   return NVIT_OK;
 }

@@ -101,6 +101,12 @@ class _Runtime:
         self.use_side = os.environ.get("NVIT_SIDE_STREAM", "0") == "1"  # measured: no gain (the persistent GEMMs fill registers + LDS)
         self.side = None
         self._keep: List[Tensor] = []
+        # bf16 mode: the two data-gradient GEMMs that used to accumulate into the fp32 residual-stream gradient (c_fc
+        # and q/k/v) store bf16 once and the next lerp_bwd adds it while it reads its incoming gradient anyway
+        # (nvit_lerp_bwd dout_add).  `carry` hands the q/k/v addend to the backward of the PREVIOUS block of the chain
+        # built by ViT.forward: (index of the consumer, tensor); -1 = the cross-attention block.
+        self.lo_dgrad = os.environ.get("NVIT_LO_DGRAD", "1") == "1"
+        self.carry = None
 
     def on_side(self, fn, *keep):
         """Run fn() (kernel launches only; outputs must be pre-allocated by the caller) on the side stream,
@@ -264,13 +270,31 @@ def _lo(rt: _Runtime, x: Tensor, x_lo: Tensor) -> Tensor:
     return x.detach() if rt.dt == F32 else x_lo
 
 
+def _take_carry(rt: "_Runtime", idx: int, chained: bool, dout: Tensor) -> Optional[Tensor]:
+    """The bf16 addend the backward of block idx+1 left for this node (see _Runtime.carry), or None.  It is only valid
+    for the very gradient tensor that node returned: anything else (a hook that replaced the gradient, a second consumer
+    whose gradient autograd summed in) would silently drop or misplace it, so it is checked, not assumed."""
+    c, rt.carry = rt.carry, None
+    if c is None:
+        return None
+    want, dx, add = c
+    if not chained or want != idx:
+        raise RuntimeError("nvit_amd: pending q/k/v data gradient was not consumed by the block it was produced for")
+    if dout.data_ptr() != dx.data_ptr():
+        # autograd handed this node a different tensor (gradient hook / extra consumer of the block input): fold the
+        # addend in explicitly and carry on with the plain path
+        dout.add_(add.float())
+        return None
+    return add
+
+
 class _BlockFn(torch.autograd.Function):
     """One nGPT block (+ norm_skip): reference Block.forward (model.py:92-169) followed by
     Block.norm_skip (model.py:84-87) as called at model.py:450-452."""
 
     @staticmethod
     def forward(ctx, x, x_lo, rt, idx, with_skip, impl, skip_param, attn_alpha, mlp_alpha, sqk, suv, wq, wk, wv, wo,
-                wfc, wp, bq, bk_, bv, bo, bfc, bp):
+                wfc, wp, bq, bk_, bv, bo, bfc, bp, chained=False):
         cfg = rt.model.config
         C, H = cfg.n_embd, cfg.n_head
         d = C // H
@@ -321,6 +345,7 @@ class _BlockFn(torch.autograd.Function):
         if dt == F32:
             xn_lo = xn.new_empty(0)  # placeholder: callers alias x itself in fp32 mode (see _lo())
         ctx.rt, ctx.idx, ctx.with_skip, ctx.impl, ctx.has_b = rt, idx, with_skip, impl, has_b
+        ctx.chained = bool(chained)   # called from ViT.forward's block chain: the consumer of dx is our own backward node
         ctx.qpre = qpre
         ctx.dims = (B, T, C, H, d, M)
         ctx.par = (skip_param, attn_alpha, mlp_alpha, sqk, suv, wq, wk, wv, wo, wfc, wp)   # gradient destinations
@@ -343,17 +368,19 @@ class _BlockFn(torch.autograd.Function):
         c_q, c_a = 1.0 / cfg.base_scale, 0.05 / cfg.base_scale
         pre = f"h{idx}."
         if dxn is None:
-            return (None,) * 23
+            return (None,) * 24
         dxn = dxn.contiguous()
+        lo_dgrad = rt.lo_dgrad and dt != F32
+        carry_in = _take_carry(rt, idx, ctx.chained, dxn)   # q/k/v data gradient of the block after this one (bf16), or None
         # ---- MLP half + norm_skip
         if ctx.with_skip:
             dh1, _, dy2_lo, dx, part_lam, part_skip = ops.lerp_bwd(dt, dxn, h1, y2, mlp_alpha, c_a, x, skip_param,
-                                                                   None, False, False, True)
+                                                                   None, False, False, True, dout_add=carry_in)
             dskip = rt.grad_buf((p_skip,), p_skip.shape)
             ops.colsum_reduce(part_skip, dskip, False)
         else:
             dh1, _, dy2_lo, _, part_lam, _ = ops.lerp_bwd(dt, dxn, h1, y2, mlp_alpha, c_a, None, None, None, False,
-                                                          False, True)
+                                                          False, True, dout_add=carry_in)
             dx, dskip = None, None
         d_mlp_alpha = _param_grad_alpha(rt, part_lam, p_malpha, c_a)
         gscale = math.sqrt(C)
@@ -367,17 +394,21 @@ class _BlockFn(torch.autograd.Function):
         rt.on_side(lambda: ops.gemm_tn(dy2_lo, xm, g_wp, M, C, 4 * C), dy2_lo, xm)
         g_bp = _bias_grad(dy2_lo, M, C) if ctx.has_b else None
         d_suv = _param_grad_scaled(rt, part_suv, p_suv, 1.0)
-        ops.gemm_nt(duv, sh[pre + "fc.Wt"], M, C, 8 * C, out=dh1, accumulate=True)
+        if lo_dgrad:
+            dh1_add = ops.gemm_nt(duv, sh[pre + "fc.Wt"], M, C, 8 * C, out_dtype=td)   # bf16, added by the next lerp_bwd
+        else:
+            dh1_add = None
+            ops.gemm_nt(duv, sh[pre + "fc.Wt"], M, C, 8 * C, out=dh1, accumulate=True)
         g_wfc = rt.grad_buf((p_wfc,), (8 * C, C))
         rt.on_side(lambda: ops.gemm_tn(duv, h1_lo, g_wfc, M, 8 * C, C, perm=1), duv, h1_lo)
         g_bfc = _bias_grad(duv, M, 8 * C, perm=1) if ctx.has_b else None
         # ---- attention half
         if dx is None:
             dx, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dh1, x, y, attn_alpha, c_a, None, None, None, False,
-                                                        False, True)
+                                                        False, True, dout_add=dh1_add)
         else:
             dx, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dh1, x, y, attn_alpha, c_a, None, None, dx, True, False,
-                                                        True)
+                                                        True, dout_add=dh1_add)
         d_attn_alpha = _param_grad_alpha(rt, part_lam, p_aalpha, c_a)
         do = ops.gemm_nt(dy_lo, sh[pre + "o.Wt"], M, C, C, out_dtype=td)
         g_wo = rt.grad_buf((p_wo,), (C, C))
@@ -395,7 +426,12 @@ class _BlockFn(torch.autograd.Function):
             part_sqk = ops.qknorm_bwd(dt, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q, dqkv, 3 * C, dqkv[:, C:], 3 * C,
                                       dqkv[:, 2 * C:], 3 * C, B, T, H, d)
             d_sqk = _param_grad_scaled(rt, part_sqk, p_sqk, c_q)
-        ops.gemm_nt(dqkv, sh[pre + "qkv.Wt"], M, C, 3 * C, out=dx, accumulate=True)
+        if lo_dgrad and ctx.chained:
+            # the consumer of dx is the backward node of the previous block (or of the cross-attention block): hand it
+            # the q/k/v data gradient as a separate bf16 addend instead of read-modify-writing dx
+            rt.carry = (idx - 1, dx, ops.gemm_nt(dqkv, sh[pre + "qkv.Wt"], M, C, 3 * C, out_dtype=td))
+        else:
+            ops.gemm_nt(dqkv, sh[pre + "qkv.Wt"], M, C, 3 * C, out=dx, accumulate=True)
         g_qkv = rt.grad_buf((p_wq, p_wk, p_wv), (3 * C, C))   # one stacked GEMM output = three adjacent bucket slices
         rt.on_side(lambda: ops.gemm_tn(dqkv, x_lo, g_qkv, M, 3 * C, C), dqkv, x_lo)
         g_bqkv = _bias_grad(dqkv, M, 3 * C) if ctx.has_b else None
@@ -406,14 +442,15 @@ class _BlockFn(torch.autograd.Function):
         else:
             gbq = gbk = gbv = None
         return (dx, None, None, None, None, None, dskip, d_attn_alpha, d_mlp_alpha, d_sqk, d_suv, gq, gk, gv, g_wo,
-                g_wfc, g_wp, gbq, gbk, gbv, g_bo, g_bfc, g_bp)
+                g_wfc, g_wp, gbq, gbk, gbv, g_bo, g_bfc, g_bp, None)
 
 
 class _CrossFn(torch.autograd.Function):
     """CrossAttentionBlock.forward (reference model.py:219-275), nViT branch."""
 
     @staticmethod
-    def forward(ctx, loc, glo, loc_lo, glo_lo, rt, impl, attn_alpha, sqk, wq, wk, wv, wproj, wout, bq, bk_, bv, bproj, bout):
+    def forward(ctx, loc, glo, loc_lo, glo_lo, rt, impl, attn_alpha, sqk, wq, wk, wv, wproj, wout, bq, bk_, bv, bproj, bout,
+                chained=False):
         cfg = rt.model.config
         C, H = cfg.n_embd, cfg.n_head
         d = C // H
@@ -457,6 +494,7 @@ class _CrossFn(torch.autograd.Function):
         if dt == F32:
             x_lo = x.new_empty(0)
         ctx.rt, ctx.impl, ctx.has_b = rt, impl, has_b
+        ctx.chained = bool(chained)
         ctx.qpre = qpre
         ctx.dims = (B, T, C, H, d, M)
         ctx.par = (attn_alpha, sqk, wq, wk, wv, wproj, wout)
@@ -468,7 +506,7 @@ class _CrossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx, _unused):
         if dx is None:
-            return (None,) * 18
+            return (None,) * 19
         loc, glo, loc_lo, glo_lo, qh, kh, vh, rq, rk, o, lse, pr, g, y, attn_alpha, sqk = ctx.saved_tensors
         rt, impl = ctx.rt, ctx.impl
         B, T, C, H, d, M = ctx.dims
@@ -478,8 +516,10 @@ class _CrossFn(torch.autograd.Function):
         sh = rt.sh
         dev = loc.device
         c_q, c_a = 1.0 / cfg.base_scale, 0.05 / cfg.base_scale
-        dloc, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dx.contiguous(), loc, y, attn_alpha, c_a, None, None, None,
-                                                      False, False, True)
+        dx = dx.contiguous()
+        carry_in = _take_carry(rt, -1, ctx.chained, dx)
+        dloc, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dx, loc, y, attn_alpha, c_a, None, None, None,
+                                                      False, False, True, dout_add=carry_in)
         d_alpha = _param_grad_alpha(rt, part_lam, p_alpha, c_a)
         if ops.fusable(dt, M, C, C):
             dpr, _ = ops.gemm_nt_swiglu_bwd(dy_lo, sh["x.out.Wt"], pr, M, C, C, None, 1.0)
@@ -514,7 +554,7 @@ class _CrossFn(torch.autograd.Function):
         else:
             g_bq = gbk = gbv = None
         return (dloc, dglo, None, None, None, None, d_alpha, d_sqk, g_wq, g_wkv[:C], g_wkv[C:], g_wproj, g_wout, g_bq, gbk, gbv,
-                g_bproj, g_bout)
+                g_bproj, g_bout, None)
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -737,10 +777,10 @@ class Block(nn.Module):
                 self.key.weight, self.value.weight, self.att_c_proj.weight, self.c_fc.weight, self.mlp_c_proj.weight,
                 b(self.query), b(self.key), b(self.value), b(self.att_c_proj), b(self.c_fc), b(self.mlp_c_proj))
 
-    def _run(self, x: Tensor, x_lo: Tensor, with_skip: bool):
+    def _run(self, x: Tensor, x_lo: Tensor, with_skip: bool, chained: bool = False):
         model, idx = self._owner
         rt = model._rt
-        xn, xn_lo = _BlockFn.apply(x, x_lo, rt, idx, with_skip, model._attn_impl(), *self._args())
+        xn, xn_lo = _BlockFn.apply(x, x_lo, rt, idx, with_skip, model._attn_impl(), *self._args(), chained)
         return xn, _lo(rt, xn, xn_lo)
 
     def norm_skip(self, source: Tensor, target: Tensor) -> Tensor:
@@ -793,9 +833,10 @@ class CrossAttentionBlock(nn.Module):
                 self.proj.weight, self.out_proj.weight, b(self.q_local), b(self.k_global), b(self.v_global),
                 b(self.proj), b(self.out_proj))
 
-    def _run(self, loc: Tensor, glo: Tensor, loc_lo: Optional[Tensor] = None, glo_lo: Optional[Tensor] = None):
+    def _run(self, loc: Tensor, glo: Tensor, loc_lo: Optional[Tensor] = None, glo_lo: Optional[Tensor] = None,
+             chained: bool = False):
         model = self._owner
-        x, x_lo = _CrossFn.apply(loc, glo, loc_lo, glo_lo, model._rt, model._attn_impl(), *self._args())
+        x, x_lo = _CrossFn.apply(loc, glo, loc_lo, glo_lo, model._rt, model._attn_impl(), *self._args(), chained)
         return x, _lo(model._rt, x, x_lo)
 
     def forward(self, local: Tensor, global_: Tensor) -> Tensor:
@@ -848,7 +889,8 @@ class ViT(nn.Module):
         # bf16 mode: store the branch outputs y (the nn.Linear results that enter the LERP) in bf16, as the reference's own
         # autocast path does (every nn.Linear returns bf16).  y only enters the stream through
         # lam * (nrm(y) - nrm(h)) with lam ~ 0.05, so its rounding adds ~5e-6 rms to a stream error of ~2e-5.
-        self.y_bf16 = os.environ.get("NVIT_Y_BF16", "0") == "1"
+        # (default since round 3: -0.4..1 ms per Base step, and the matched CPU emulation rounds y at the same point)
+        self.y_bf16 = os.environ.get("NVIT_Y_BF16", "1") == "1"
         object.__setattr__(self, "_rt", _Runtime(self))
         object.__setattr__(self, "_node_sync", None)   # set by DataParallel: averages SOM nodes across ranks
         object.__setattr__(self, "_taps", None)        # tests: dict that receives the residual stream after each block
@@ -1016,16 +1058,17 @@ class ViT(nn.Module):
             aux["kohonen_smoothness"] = self.compute_smoothness_loss(local_idx, global_idx)
             aux["local_quantization"] = HuberFn.apply(lrep2, loc)
             aux["global_quantization"] = HuberFn.apply(grep2, glo)
-            x, x_lo = self.cross_attention._run(local_new, global_new)
+            x, x_lo = self.cross_attention._run(local_new, global_new, chained=True)
             if self._taps is not None:
                 self._taps["lidx"], self._taps["gidx"] = local_idx.detach(), global_idx.detach()
         else:
-            x, x_lo = self.cross_attention._run(loc, glo, loc_lo, glo_lo)
+            x, x_lo = self.cross_attention._run(loc, glo, loc_lo, glo_lo, chained=True)
+        rt.carry = None
         taps = self._taps
         if taps is not None:
             taps["loc"], taps["glo"], taps["x0"] = loc.detach(), glo.detach(), x.detach()
         for i, blk in enumerate(self.transformer.h):
-            x, x_lo = blk._run(x, x_lo, True)
+            x, x_lo = blk._run(x, x_lo, True, chained=True)
             if taps is not None:
                 taps[f"x{i + 1}"] = x.detach()
         logits = _HeadFn.apply(x, rt, self.mlp_head[0].weight, self.mlp_head[0].bias, self.mlp_head[1].weight,

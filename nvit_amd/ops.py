@@ -199,8 +199,12 @@ def lerp_fwd(dt: int, h: Tensor, y: Tensor, alpha: Tensor, c_a: float, skip_x: O
 
 
 def lerp_bwd(dt: int, dout: Tensor, h: Tensor, y: Tensor, alpha: Tensor, c_a: float, skip_x: Optional[Tensor],
-             skip: Optional[Tensor], dh: Optional[Tensor], accum_dh: bool, want_dy_f32: bool, want_dy_lo: bool):
-    """-> dh, dy_f32|None, dy_lo|None, dskip_x|None, part_dlam [nblk,C], part_dskip|None"""
+             skip: Optional[Tensor], dh: Optional[Tensor], accum_dh: bool, want_dy_f32: bool, want_dy_lo: bool,
+             dout_add: Optional[Tensor] = None):
+    """-> dh, dy_f32|None, dy_lo|None, dskip_x|None, part_dlam [4*nblk,C], part_dskip|None.
+    dout_add: optional bf16 [M,C] added to dout inside the kernel (a data-gradient GEMM's output)."""
+    if dout_add is not None and (dout_add.dtype != torch.bfloat16 or dout_add.shape != h.shape or not dout_add.is_contiguous()):
+        raise ValueError("lerp_bwd: dout_add must be a contiguous bf16 [M,C] tensor")
     M, Cc = h.shape
     dev = h.device
     nblk = min(PART_BLOCKS, math.ceil(M / 4))
@@ -210,9 +214,9 @@ def lerp_bwd(dt: int, dout: Tensor, h: Tensor, y: Tensor, alpha: Tensor, c_a: fl
     dy = torch.empty_like(h) if want_dy_f32 else None
     dy_lo = torch.empty((M, Cc), device=dev, dtype=tdtype(dt)) if want_dy_lo else None
     dskip_x = torch.empty_like(h) if skip_x is not None else None
-    part = torch.empty((nblk, Cc), device=dev, dtype=torch.float32)
-    pskip = torch.empty((nblk,), device=dev, dtype=torch.float32) if skip_x is not None else None
-    check(_lib.load().nvit_lerp_bwd(dt, _p(dout), _p(h), _p(y), dt_of(y), _p(alpha), c_a, _p(skip_x), _p(skip),
+    part = torch.empty((4 * nblk, Cc), device=dev, dtype=torch.float32)      # one row of column partials per wave
+    pskip = torch.empty((4 * nblk,), device=dev, dtype=torch.float32) if skip_x is not None else None
+    check(_lib.load().nvit_lerp_bwd(dt, _p(dout), _p(dout_add), _p(h), _p(y), dt_of(y), _p(alpha), c_a, _p(skip_x), _p(skip),
                                     _p(dh), int(accum_dh), _p(dy), _p(dy_lo), _p(dskip_x), _p(part), _p(pskip),
                                     nblk, M, Cc, _s()), "nvit_lerp_bwd")
     return dh, dy, dy_lo, dskip_x, part, pskip

@@ -61,17 +61,25 @@ class KernelRounding:
         conventions is not a power of two, so every probability rounds independently of the row-maximum form.
       * on the fused path (n_embd % 256 == 0) the q projection leaves its GEMM epilogue pre-scaled by sqrt(d)*log2(e)
         (one rounding of q_hat*prescale instead of rounding q_hat and scaling the fp32 score).
+      * `y_bf16`: the branch outputs y (att_c_proj / mlp_c_proj / out_proj results, the second LERP input) are stored in
+        bf16, as the reference's own autocast nn.Linear returns them.
     `acc64=True` additionally accumulates every matrix product in float64 (same operand roundings, different summation
     order/accuracy): the distance between the two is the noise floor of 'same rounding points, other summation order'.
-    With attn_conv="rowmax" and acc64=False this is exactly `bf16_round`."""
+    With attn_conv="rowmax", acc64=False and y_bf16=False this is exactly `bf16_round`."""
 
-    def __init__(self, attn_conv: str = "bound", acc64: bool = False) -> None:
+    def __init__(self, attn_conv: str = "bound", acc64: bool = False, y_bf16: bool = True) -> None:
         assert attn_conv in ("bound", "rowmax")
         self.attn_conv = attn_conv
         self.acc64 = acc64
+        self.y_bf16 = y_bf16
 
     def __call__(self, t: Tensor) -> Tensor:
         return bf16_round(t)
+
+
+def _ylo(y: Tensor, lowp: LowP) -> Tensor:
+    """Storage rounding of a branch output (see KernelRounding.y_bf16)."""
+    return lowp(y) if getattr(lowp, "y_bf16", False) else y
 
 
 def _mm(a: Tensor, b: Tensor, lowp: LowP) -> Tensor:
@@ -175,7 +183,7 @@ def cross_block(p: Params, cfg, local: Tensor, global_: Tensor, lowp: LowP) -> T
     C = cfg.n_embd
     u, g = o[..., :C], o[..., C:]
     o = u * (g * torch.sigmoid(g))
-    o = linear(o, p[pre + "out_proj.weight"], _b(p, pre + "out_proj.bias"), lowp)
+    o = _ylo(linear(o, p[pre + "out_proj.weight"], _b(p, pre + "out_proj.bias"), lowp), lowp)
     return lerp(local, o, p[pre + "attn_alpha"], c_a)
 
 
@@ -188,13 +196,13 @@ def block(p: Params, cfg, i: int, x: Tensor, lowp: LowP) -> Tensor:
     k = linear(x, p[pre + "key.weight"], _b(p, pre + "key.bias"), lowp)
     v = linear(x, p[pre + "value.weight"], _b(p, pre + "value.bias"), lowp)
     o = attend(q, k, v, p[pre + "sqk"] * c_q, cfg.n_head, lowp)
-    y = linear(o, p[pre + "att_c_proj.weight"], _b(p, pre + "att_c_proj.bias"), lowp)
+    y = _ylo(linear(o, p[pre + "att_c_proj.weight"], _b(p, pre + "att_c_proj.bias"), lowp), lowp)
     h1 = lerp(x, y, p[pre + "attn_alpha"], c_a)
     uv = linear(h1, p[pre + "c_fc.weight"], _b(p, pre + "c_fc.bias"), lowp)
     uv = uv * (p[pre + "suv"] * (1.0 * math.sqrt(C)))
     u, g = uv[..., : 4 * C], uv[..., 4 * C:]
     xm = u * (g * torch.sigmoid(g))
-    y2 = linear(xm, p[pre + "mlp_c_proj.weight"], _b(p, pre + "mlp_c_proj.bias"), lowp)
+    y2 = _ylo(linear(xm, p[pre + "mlp_c_proj.weight"], _b(p, pre + "mlp_c_proj.bias"), lowp), lowp)
     h2 = lerp(h1, y2, p[pre + "mlp_alpha"], c_a)
     return nrm(h2 * p[pre + "skip_param"] + x)
 
