@@ -52,7 +52,7 @@ def main():
 
     t0 = time.time()
     runs = {"fp32": oracle(None),
-            "E_rowmax": oracle(O.bf16_round),
+            "E_rowmax": oracle(O.KernelRounding("rowmax")),
             "E_bound": oracle(O.KernelRounding("bound")),
             "E_rowmax_acc64": oracle(O.KernelRounding("rowmax", acc64=True)),
             "E_bound_acc64": oracle(O.KernelRounding("bound", acc64=True))}
