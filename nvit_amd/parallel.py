@@ -167,7 +167,10 @@ class DataParallel(nn.Module):
         a separate `div_` was 479 MB of read + write per Base step on the critical stream); gloo (CPU tests and the
         one-GPU DP tests) has no AVG, there the scale runs before the sum."""
         if self._avg:
-            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+            try:
+                return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+            except (RuntimeError, ValueError):   # a communicator without AVG: scale, then sum (decided once, on every rank alike)
+                self._avg = False
         t.div_(self.world)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
