@@ -127,8 +127,10 @@ __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
 #ifndef NVIT_LERP_BWD_WAVES
 #define NVIT_LERP_BWD_WAVES 1
 #endif
-template <int NV, typename TY, typename TL, bool ADD>
-__global__ __launch_bounds__(256, NVIT_LERP_BWD_WAVES) void lerp_bwd_kernel(LerpBwdArgs a) {
+// SKIP (norm_skip fused behind the LERP: the MLP half of a block) and ACCUM (dh += : the attention half, whose dh already
+// holds the gradient of the skip path) are template switches as well: a row then keeps 5 vectors in flight instead of 6.
+template <int NV, typename TY, typename TL, bool ADD, bool SKIP, bool ACCUM>
+__global__ __launch_bounds__(256, (NV <= 3 ? NVIT_LERP_BWD_WAVES : 1)) void lerp_bwd_kernel(LerpBwdArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   RowVec<NV> lam, dlam;
   row_load<NV, float>(lam, a.alpha, a.C, lane);
@@ -138,24 +140,35 @@ __global__ __launch_bounds__(256, NVIT_LERP_BWD_WAVES) void lerp_bwd_kernel(Lerp
 #pragma unroll
     for (int e = 0; e < 4; ++e) lam.v[i][e] = fabsf(lam.v[i][e] * a.c_a);
   }
-  const float skip = a.skip_x ? a.skip[0] : 0.f;
+  const float skip = SKIP ? a.skip[0] : 0.f;
   float dskip_acc = 0.f;
   for (int m = blockIdx.x * ROW_WAVES + wid; m < a.M; m += gridDim.x * ROW_WAVES) {
-    RowVec<NV> av, bv, g, t, old, ga;   // av: h then a = nrm(h); bv: y then b = nrm(y); g: incoming gradient, then d(lerp out), then dr
+    RowVec<NV> av, bv, g, t, old;   // av: h then a = nrm(h); bv: y then b = nrm(y); g: incoming gradient, then d(lerp out), then dr
+    uint2 ga[NV];                    // the bf16 addend stays packed until it is added (half the registers in flight)
     const size_t ro = (size_t)m * a.C;
     // every load of the row goes out before the first reduction: one memory round trip per row, not two or three
     row_load<NV, float>(av, a.h + ro, a.C, lane);
     row_load<NV, TY>(bv, reinterpret_cast<const TY*>(a.y) + ro, a.C, lane);
     row_load<NV, float>(g, a.dout + ro, a.C, lane);
-    if constexpr (ADD) row_load<NV, bf16>(ga, a.dout_add + ro, a.C, lane);
-    if (a.skip_x) row_load<NV, float>(t, a.skip_x + ro, a.C, lane);
-    if (a.accum_dh) row_load<NV, float>(old, a.dh + ro, a.C, lane);
+    if constexpr (ADD) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        ga[i] = c < a.C ? *reinterpret_cast<const uint2*>(a.dout_add + ro + c) : make_uint2(0u, 0u);
+      }
+    }
+    if constexpr (SKIP) row_load<NV, float>(t, a.skip_x + ro, a.C, lane);
     if constexpr (ADD) {   // incoming gradient = dout + dout_add: the GEMM that produced dout_add need not read-modify-write dout
 #pragma unroll
-      for (int i = 0; i < NV; ++i) g.v[i] += ga.v[i];
+      for (int i = 0; i < NV; ++i) {
+        const bf16x4 q = __builtin_bit_cast(bf16x4, ga[i]);
+        g.v[i] += (f32x4){(float)q[0], (float)q[1], (float)q[2], (float)q[3]};
+      }
     }
     const float rsx = 1.0f / sqrtf(row_dot<NV>(av, av));
     const float rsy = 1.0f / sqrtf(row_dot<NV>(bv, bv));
+    // (the old dh values are needed only at the store: requested here, they arrive under the remaining reductions)
+    if constexpr (ACCUM) row_load<NV, float>(old, a.dh + ro, a.C, lane);
     float ss = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -166,7 +179,7 @@ __global__ __launch_bounds__(256, NVIT_LERP_BWD_WAVES) void lerp_bwd_kernel(Lerp
     }
     const float rsr = 1.0f / sqrtf(wave_sum(ss));
 #define NVIT_LERP_O(i_) ((av.v[i_] + lam.v[i_] * (bv.v[i_] - av.v[i_])) * rsr)   /* o = lerp output (unit norm), recomputed */
-    if (a.skip_x) {
+    if constexpr (SKIP) {
       // t = o*skip + xs ; out = t/|t| ; dt = (g - out<out,g>)/|t| ; do = skip*dt ; dxs = dt ; dskip += <dt,o>
       float st = 0.f;
 #pragma unroll
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(256, NVIT_LERP_BWD_WAVES) void lerp_bwd_kernel(Lerp
       const f32x4 db = lam.v[i] * g.v[i];
       f32x4 dh = ((g.v[i] - db) - av.v[i] * ada) * rsx;
       const f32x4 dy = (db - bv.v[i] * bdb) * rsy;
-      if (a.accum_dh) dh += old.v[i];
+      if constexpr (ACCUM) dh += old.v[i];
       if (c < a.C) {
         store4<float>(a.dh + ro + c, dh);
         if (a.dy) store4<float>(a.dy + ro + c, dy);
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(256, NVIT_LERP_BWD_WAVES) void lerp_bwd_kernel(Lerp
   // column partials: one row per wave (fixed layout, reduced in fixed order by nvit_colsum_reduce)
   const size_t prow = (size_t)blockIdx.x * ROW_WAVES + wid;
   row_store<NV, float>(dlam, a.part_dlam + prow * a.C, a.C, lane);
-  if (a.skip_x && lane == 0) a.part_dskip[prow] = dskip_acc;
+  if (SKIP && lane == 0) a.part_dskip[prow] = dskip_acc;
 }
 
 // ------------------------------------------------------------------------------ standalone norm_skip
@@ -696,12 +709,23 @@ extern "C" int nvit_lerp_bwd(int dt, const float* dout, const void* dout_add, co
   const double lb_bytes = (double)M * C * (4.0 + 4.0 + (y_dt == NVIT_F32 ? 4.0 : 2.0) + 4.0 + (dy ? 4.0 : 0.0) + (dy_lo ? (dt == NVIT_F32 ? 4.0 : 2.0) : 0.0) +
                                            (skip_x ? 8.0 : 0.0) + (accum_dh ? 4.0 : 0.0) + (dout_add ? 2.0 : 0.0));
   ProfScope ps(NVIT_KID_ROWOPS, 0.0, lb_bytes, s);
-#define NVIT_LERP_BWD_LAUNCH(TY_, TL_)                                                                       \
-  {                                                                                                          \
-    if (dout_add)                                                                                            \
-      hipLaunchKernelGGL((lerp_bwd_kernel<NV, TY_, TL_, true>), dim3(nblk), dim3(256), 0, s, a);             \
-    else                                                                                                     \
-      hipLaunchKernelGGL((lerp_bwd_kernel<NV, TY_, TL_, false>), dim3(nblk), dim3(256), 0, s, a);            \
+#define NVIT_LERP_BWD_LAUNCH3(TY_, TL_, ADD_)                                                                          \
+  {                                                                                                                    \
+    if (skip_x && accum_dh)                                                                                            \
+      hipLaunchKernelGGL((lerp_bwd_kernel<NV, TY_, TL_, ADD_, true, true>), dim3(nblk), dim3(256), 0, s, a);           \
+    else if (skip_x)                                                                                                   \
+      hipLaunchKernelGGL((lerp_bwd_kernel<NV, TY_, TL_, ADD_, true, false>), dim3(nblk), dim3(256), 0, s, a);          \
+    else if (accum_dh)                                                                                                 \
+      hipLaunchKernelGGL((lerp_bwd_kernel<NV, TY_, TL_, ADD_, false, true>), dim3(nblk), dim3(256), 0, s, a);          \
+    else                                                                                                               \
+      hipLaunchKernelGGL((lerp_bwd_kernel<NV, TY_, TL_, ADD_, false, false>), dim3(nblk), dim3(256), 0, s, a);         \
+  }
+#define NVIT_LERP_BWD_LAUNCH(TY_, TL_)          \
+  {                                             \
+    if (dout_add)                               \
+      NVIT_LERP_BWD_LAUNCH3(TY_, TL_, true)     \
+    else                                        \
+      NVIT_LERP_BWD_LAUNCH3(TY_, TL_, false)    \
   }
   DISPATCH_NV(C, {
     if (y_dt == NVIT_F32 && dt == NVIT_F32)
@@ -714,6 +738,7 @@ extern "C" int nvit_lerp_bwd(int dt, const float* dout, const void* dout_add, co
       NVIT_LERP_BWD_LAUNCH(bf16, bf16)
   });
 #undef NVIT_LERP_BWD_LAUNCH
+#undef NVIT_LERP_BWD_LAUNCH3
   NVIT_CHECK_LAUNCH("lerp_bwd");
   return NVIT_OK;
 }
