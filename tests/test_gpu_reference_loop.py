@@ -207,3 +207,32 @@ def test_public_api_numerics_vs_oracle():
     pw = m.cross_attention.q_local.weight.grad.cpu()
     rw = p["cross_attention.q_local.weight"].grad
     assert (pw - rw).abs().max().item() < 2e-4 * rw.abs().max().item() + 1e-8
+
+
+def test_rmsnorm_module_dtypes_vs_reference_formula():
+    """`RMSNorm` (reference model.py:170-182; dead on the nViT path, a working public module): computed in fp32, the
+    normalised value cast back to the INPUT dtype, then multiplied by the fp32 weight - for fp32 and bf16 inputs."""
+    from nvit.model import RMSNorm
+    g = torch.Generator().manual_seed(3)
+    mod = RMSNorm(256).cuda()
+    with torch.no_grad():
+        mod.weight.copy_(torch.rand(256, generator=g) + 0.5)
+    x = torch.randn(5, 7, 256, generator=g)
+    w = mod.weight.detach().cpu()
+
+    def ref(t):
+        t32 = t.float()
+        n = t32 * torch.rsqrt(t32.pow(2).mean(-1, keepdim=True) + mod.eps)
+        return w * n.to(t.dtype)
+
+    out = mod(x.cuda())
+    assert out.dtype == torch.float32 and (out.cpu() - ref(x)).abs().max().item() < 2e-6
+    xb = x.bfloat16()
+    outb = mod(xb.cuda())
+    assert outb.dtype == ref(xb).dtype
+    assert (outb.float().cpu() - ref(xb).float()).abs().max().item() < 2e-2   # one bf16 ulp of values up to ~4
+    xg = x.cuda().requires_grad_(True)
+    mod(xg).sum().backward()
+    xr = x.clone().requires_grad_(True)
+    ref(xr).sum().backward()
+    assert (xg.grad.cpu() - xr.grad).abs().max().item() < 2e-5
