@@ -175,6 +175,9 @@ int nvit_lerp_fwd(int dt, const float* h, const void* y, int y_dt, const float* 
  * dout_add (bf16 [M,C] or NULL): the incoming gradient is dout + dout_add - lets the data-gradient GEMM that produced
  * dout_add store bf16 once instead of read-modify-writing the fp32 dout (the reference's autocast nn.Linear hands its
  * input gradient back in bf16 as well). */
+/* nvit_lerp_bwd_blocks: the nblk that fills the device exactly once for the kernel variant these options select (0 on
+ * error); callers size the partial buffers with it. */
+int nvit_lerp_bwd_blocks(int dt, int y_dt, int C, int has_add, int has_skip, int accum);
 int nvit_lerp_bwd(int dt, const float* dout, const void* dout_add, const float* h, const void* y, int y_dt, const float* alpha,
                   float c_a, const float* skip_x, const float* skip, float* dh, int accum_dh, float* dy,
                   void* dy_lo, float* dskip_x, float* part_dlam, float* part_dskip, int nblk, int M, int C,

@@ -43,6 +43,7 @@ SIGNATURES = {
     "nvit_gemm_nt_qknorm": [_i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "nvit_gemm_tn": [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i64, _i, _i, _vp],
     "nvit_lerp_fwd": [_i, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "nvit_lerp_bwd_blocks": [_i, _i, _i, _i, _i, _i],
     "nvit_lerp_bwd": [_i, _vp, _vp, _vp, _vp, _i, _vp, _f, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "nvit_norm_skip_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "nvit_norm_skip_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

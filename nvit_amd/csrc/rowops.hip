@@ -696,6 +696,45 @@ extern "C" int nvit_lerp_fwd(int dt, const float* h, const void* y, int y_dt, co
   return NVIT_OK;
 }
 
+// Workgroups that are resident at once for the lerp_bwd instantiation a call with these options would launch (CUs x
+// blocks per CU from the occupancy query).  The kernel walks its rows with a grid stride, so a grid of exactly this many
+// blocks keeps every SIMD busy to the end; the round-2 default of 1024 blocks ran as 768 + 256 at C = 768 (3 waves per
+// SIMD): a second, one-third-full round (row kernels 14.9 -> 13.1 ms per Base step with the resident count).
+template <typename K>
+static int resident_blocks(K kernel) {
+  int dev = 0, per_cu = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) return 0;
+  return per_cu * prop.multiProcessorCount;
+}
+
+extern "C" int nvit_lerp_bwd_blocks(int dt, int y_dt, int C, int has_add, int has_skip, int accum) {
+  if (C % 4 != 0 || C <= 0 || C > 2048) return 0;
+  int n = 0;
+#define NVIT_LB_Q3(TY_, TL_, ADD_)                                                                   \
+  {                                                                                                  \
+    if (has_skip && accum) n = resident_blocks(lerp_bwd_kernel<NV, TY_, TL_, ADD_, true, true>);     \
+    else if (has_skip) n = resident_blocks(lerp_bwd_kernel<NV, TY_, TL_, ADD_, true, false>);        \
+    else if (accum) n = resident_blocks(lerp_bwd_kernel<NV, TY_, TL_, ADD_, false, true>);           \
+    else n = resident_blocks(lerp_bwd_kernel<NV, TY_, TL_, ADD_, false, false>);                     \
+  }
+#define NVIT_LB_Q(TY_, TL_)                \
+  {                                        \
+    if (has_add) NVIT_LB_Q3(TY_, TL_, true) \
+    else NVIT_LB_Q3(TY_, TL_, false)       \
+  }
+  DISPATCH_NV(C, {
+    if (y_dt == NVIT_F32 && dt == NVIT_F32) NVIT_LB_Q(float, float)
+    else if (y_dt == NVIT_F32) NVIT_LB_Q(float, bf16)
+    else if (dt == NVIT_F32) NVIT_LB_Q(bf16, float)
+    else NVIT_LB_Q(bf16, bf16)
+  });
+#undef NVIT_LB_Q
+#undef NVIT_LB_Q3
+  return n > 4096 ? 4096 : n;
+}
+
 extern "C" int nvit_lerp_bwd(int dt, const float* dout, const void* dout_add, const float* h, const void* y, int y_dt, const float* alpha,
                              float c_a, const float* skip_x, const float* skip, float* dh, int accum_dh, float* dy,
                              void* dy_lo, float* dskip_x, float* part_dlam, float* part_dskip, int nblk, int M,

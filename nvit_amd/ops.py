@@ -185,6 +185,8 @@ def gemm_tn(A: Tensor, B: Tensor, G: Tensor, Mred: int, N: int, K: int, perm: in
 
 
 # ----------------------------------------------------------------------------- row ops
+_PART_BLOCKS_ENV = "NVIT_PART_BLOCKS" in os.environ
+_LERP_BWD_BLOCKS: dict = {}
 PART_BLOCKS = int(os.environ.get("NVIT_PART_BLOCKS", "1024"))   # workgroups of the backward row kernels (experiments: env)
 
 
@@ -207,10 +209,17 @@ def lerp_bwd(dt: int, dout: Tensor, h: Tensor, y: Tensor, alpha: Tensor, c_a: fl
         raise ValueError("lerp_bwd: dout_add must be a contiguous bf16 [M,C] tensor")
     M, Cc = h.shape
     dev = h.device
-    nblk = min(PART_BLOCKS, math.ceil(M / 4))
     if dh is None:
         dh = torch.empty_like(h)
         accum_dh = False
+    # grid = the workgroups resident at once for this kernel variant (a second, partly filled round of a 1024-block
+    # grid cost 1.8 ms per Base step); NVIT_PART_BLOCKS overrides
+    key = (dt, dt_of(y), Cc, dout_add is not None, skip_x is not None, bool(accum_dh))
+    nres = _LERP_BWD_BLOCKS.get(key)
+    if nres is None:
+        nres = int(_lib.load().nvit_lerp_bwd_blocks(dt, dt_of(y), Cc, int(key[3]), int(key[4]), int(key[5]))) or PART_BLOCKS
+        _LERP_BWD_BLOCKS[key] = nres
+    nblk = min(PART_BLOCKS if _PART_BLOCKS_ENV else nres, math.ceil(M / 4))
     dy = torch.empty_like(h) if want_dy_f32 else None
     dy_lo = torch.empty((M, Cc), device=dev, dtype=tdtype(dt)) if want_dy_lo else None
     dskip_x = torch.empty_like(h) if skip_x is not None else None

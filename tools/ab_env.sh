@@ -2,7 +2,6 @@
 mkdir -p gpurun_out
 run() { tag=$1; shift; env "$@" python bench.py --steps 8 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); k=d['kernel_ms_per_step']; print('$tag', d['value'], d['ms_per_step'], 'nt', k['gemm_nt'], 'rowops', k['rowops'], 'tn', k['gemm_tn'])"; }
 for r in 1 2 3; do
-run new A=1
-run no_lo_dgrad NVIT_LO_DGRAD=0
-run old NVIT_LO_DGRAD=0 NVIT_Y_BF16=0
+run auto A=1
+run pb1024 NVIT_PART_BLOCKS=1024
 done
