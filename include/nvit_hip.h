@@ -223,6 +223,11 @@ int nvit_swiglu_bwd(int dt, const void* dx, const void* uv, const float* suv, fl
  * (d|alpha c_a| -> d alpha); kind 2: plain*scale written to out[perm1(n)] (SwiGLU interleave -> natural order). */
 int nvit_colsum_reduce(const float* part, int nblk, int N, float* out, int accumulate, int kind, const float* ref,
                        float scale, void* stream);
+/* nvit_colsum_reduce_multi: up to 8 such reductions in ONE launch (host arrays of n entries; pointers as int64).  An item
+ * may name a second partial array part_b (0 = none) whose reduced, scaled sum is added after the first one's. */
+int nvit_colsum_reduce_multi(const int64_t* part, const int* nblk, const int64_t* part_b, const int* nblk_b, const int* N,
+                             const int64_t* out, const int* accumulate, const int* kind, const int64_t* ref,
+                             const float* scale, int n, void* stream);
 /* nvit_colsum: out[n] (+)= scale * sum_r a[r,n] * (b ? b[r,n] : 1) over R rows; a,b fp32 or dt (a_dt,b_dt);
  * `period`>0 folds rows modulo period: out[(r%period), n] (pos-embed gradients). */
 int nvit_colsum(const void* a, int a_dt, int lda, const void* b, int b_dt, int ldb, int R, int N, int period,

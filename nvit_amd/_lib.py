@@ -52,6 +52,7 @@ SIGNATURES = {
                         _i, _i, _vp],
     "nvit_swiglu_fwd": [_i, _vp, _vp, _f, _vp, _i, _i, _vp],
     "nvit_swiglu_bwd": [_i, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _vp],
+    "nvit_colsum_reduce_multi": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "nvit_colsum_reduce": [_vp, _i, _i, _vp, _i, _i, _vp, _f, _vp],
     "nvit_colsum": [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _f, _vp],
     "nvit_cast": [_vp, _vp, _i, _i64, _vp],

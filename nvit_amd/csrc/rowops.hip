@@ -520,6 +520,81 @@ __global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* part, 
   out[dst] = accumulate ? out[dst] + s : s;
 }
 
+// Several reductions of the kind above in ONE launch (the six parameter-gradient reductions of a block's backward were
+// six ~12 us launches on the critical stream, 0.9 ms per Base step).  An item may have a second partial array whose
+// reduced, scaled sum is added after the first one's (fixed order: e.g. the q and k contributions to d sqk).
+constexpr int CSR_MAX_ITEMS = 8;
+struct CsrItem {
+  const float* part;
+  const float* part_b;   // optional second partial array (same N), or NULL
+  const float* ref;
+  float* out;
+  int nblk, nblk_b, N, accumulate, kind, block0;   // block0: first workgroup of this item in the launch
+  float scale;
+};
+struct CsrBatch {
+  CsrItem it[CSR_MAX_ITEMS];
+  int n;
+};
+
+__device__ __forceinline__ float csr_column(const float* part, int nblk, int N, int n, int rg) {
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = rg;
+  for (; b + 3 * CSR_RG < nblk; b += 4 * CSR_RG) {
+    s0 += part[(size_t)b * N + n];
+    s1 += part[(size_t)(b + CSR_RG) * N + n];
+    s2 += part[(size_t)(b + 2 * CSR_RG) * N + n];
+    s3 += part[(size_t)(b + 3 * CSR_RG) * N + n];
+  }
+  for (; b < nblk; b += CSR_RG) s0 += part[(size_t)b * N + n];
+  return (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(1024) void colsum_reduce_multi_kernel(CsrBatch bt) {
+  __shared__ float red[2][CSR_RG][33];
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < CSR_MAX_ITEMS; ++i)
+    if (i < bt.n && (int)blockIdx.x >= bt.it[i].block0) k = i;
+  // (copy of the selected item through a uniform index: the struct lives in kernel-argument memory)
+  const float* part = bt.it[k].part;
+  const float* part_b = bt.it[k].part_b;
+  const float* ref = bt.it[k].ref;
+  float* out = bt.it[k].out;
+  const int nblk = bt.it[k].nblk, nblk_b = bt.it[k].nblk_b, N = bt.it[k].N, accumulate = bt.it[k].accumulate,
+            kind = bt.it[k].kind, blk = (int)blockIdx.x - bt.it[k].block0;
+  const float scale = bt.it[k].scale;
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int n = blk * 32 + cl;
+  red[0][rg][cl] = n < N ? csr_column(part, nblk, N, n, rg) : 0.f;
+  red[1][rg][cl] = (n < N && part_b) ? csr_column(part_b, nblk_b, N, n, rg) : 0.f;
+  __syncthreads();
+  if (rg != 0 || n >= N) return;
+  float s = red[0][0][cl], sb = red[1][0][cl];
+#pragma unroll
+  for (int g = 1; g < CSR_RG; ++g) {
+    s += red[0][g][cl];
+    sb += red[1][g][cl];
+  }
+  if (kind == 1) {
+    const float r = ref[n] * scale;
+    const float f = r > 0.f ? scale : (r < 0.f ? -scale : 0.f);
+    s = s * f;
+    sb = sb * f;
+  } else {
+    s *= scale;
+    sb *= scale;
+  }
+  int dst = n;
+  if (kind == 2) {
+    const int q = n >> 5, w = n & 31, F = N >> 1;
+    dst = w < 16 ? q * 16 + w : F + q * 16 + (w - 16);
+  }
+  float r = accumulate ? out[dst] + s : s;
+  if (part_b) r += sb;
+  out[dst] = r;
+}
+
 template <typename TA, typename TB>
 __global__ void colsum_kernel(const TA* a, int lda, const TB* b, int ldb, int R, int N, int period, float* out,
                               int accumulate, float scale) {
@@ -918,6 +993,38 @@ extern "C" int nvit_colsum_reduce(const float* part, int nblk, int N, float* out
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(N, 32)), dim3(1024), 0, s, part, nblk, N, out, accumulate, kind,
                      ref, scale);
   NVIT_CHECK_LAUNCH("colsum_reduce");
+  return NVIT_OK;
+}
+
+// n <= 8 reductions in one launch.  Host arrays of n entries each; part_b[i] may be 0 (no second partial array).
+extern "C" int nvit_colsum_reduce_multi(const int64_t* part, const int* nblk, const int64_t* part_b, const int* nblk_b,
+                                        const int* N, const int64_t* out, const int* accumulate, const int* kind,
+                                        const int64_t* ref, const float* scale, int n, void* stream) {
+  NVIT_REQUIRE(n >= 1 && n <= CSR_MAX_ITEMS && part && nblk && part_b && nblk_b && N && out && accumulate && kind && ref && scale,
+               "colsum_reduce_multi: 1..%d items", CSR_MAX_ITEMS);
+  CsrBatch bt{};
+  bt.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    NVIT_REQUIRE(part[i] && out[i] && nblk[i] > 0 && N[i] > 0, "colsum_reduce_multi: item %d is empty", i);
+    NVIT_REQUIRE(kind[i] == 0 || (kind[i] == 1 && ref[i]) || (kind[i] == 2 && N[i] % 32 == 0), "colsum_reduce_multi: bad kind");
+    NVIT_REQUIRE(!part_b[i] || nblk_b[i] > 0, "colsum_reduce_multi: item %d: second partial array without rows", i);
+    CsrItem& it = bt.it[i];
+    it.part = reinterpret_cast<const float*>(part[i]);
+    it.part_b = reinterpret_cast<const float*>(part_b[i]);
+    it.ref = reinterpret_cast<const float*>(ref[i]);
+    it.out = reinterpret_cast<float*>(out[i]);
+    it.nblk = nblk[i];
+    it.nblk_b = nblk_b[i];
+    it.N = N[i];
+    it.accumulate = accumulate[i];
+    it.kind = kind[i];
+    it.scale = scale[i];
+    it.block0 = blocks;
+    blocks += cdiv(N[i], 32);
+  }
+  hipLaunchKernelGGL(colsum_reduce_multi_kernel, dim3(blocks), dim3(1024), 0, (hipStream_t)stream, bt);
+  NVIT_CHECK_LAUNCH("colsum_reduce_multi");
   return NVIT_OK;
 }
 

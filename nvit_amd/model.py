@@ -241,15 +241,16 @@ def _attn_part_fwd(rt: _Runtime, impl: int, q_src, ldq, k_src, ldk, v_src, ldv, 
     return qh, kh, vh, rq, rk, o, lse
 
 
-def _param_grad_alpha(rt, part: Tensor, alpha: Tensor, c_a: float) -> Tensor:
+def _param_grad_alpha(rt, part: Tensor, alpha: Tensor, c_a: float, batch: "ops.ReduceBatch") -> Tensor:
     g = rt.grad_buf((alpha,), alpha.shape)
-    ops.colsum_reduce(part, g, False, kind=1, ref=alpha, scale=c_a)
+    batch.add(part, g, False, kind=1, ref=alpha, scale=c_a)
     return g
 
 
-def _param_grad_scaled(rt, part: Tensor, like: Tensor, scale: float) -> Tensor:
+def _param_grad_scaled(rt, part: Tensor, like: Tensor, scale: float, batch: "ops.ReduceBatch",
+                       part_b: Optional[Tensor] = None) -> Tensor:
     g = rt.grad_buf((like,), like.shape)
-    ops.colsum_reduce(part, g, False, kind=0, scale=scale)
+    batch.add(part, g, False, kind=0, scale=scale, part_b=part_b)
     return g
 
 
@@ -371,18 +372,19 @@ class _BlockFn(torch.autograd.Function):
             return (None,) * 24
         dxn = dxn.contiguous()
         lo_dgrad = rt.lo_dgrad and dt != F32
+        red = ops.ReduceBatch()   # the block's six parameter-gradient reductions go out as one launch at the end
         carry_in = _take_carry(rt, idx, ctx.chained, dxn)   # q/k/v data gradient of the block after this one (bf16), or None
         # ---- MLP half + norm_skip
         if ctx.with_skip:
             dh1, _, dy2_lo, dx, part_lam, part_skip = ops.lerp_bwd(dt, dxn, h1, y2, mlp_alpha, c_a, x, skip_param,
                                                                    None, False, False, True, dout_add=carry_in)
             dskip = rt.grad_buf((p_skip,), p_skip.shape)
-            ops.colsum_reduce(part_skip, dskip, False)
+            red.add(part_skip, dskip, False)
         else:
             dh1, _, dy2_lo, _, part_lam, _ = ops.lerp_bwd(dt, dxn, h1, y2, mlp_alpha, c_a, None, None, None, False,
                                                           False, True, dout_add=carry_in)
             dx, dskip = None, None
-        d_mlp_alpha = _param_grad_alpha(rt, part_lam, p_malpha, c_a)
+        d_mlp_alpha = _param_grad_alpha(rt, part_lam, p_malpha, c_a, red)
         gscale = math.sqrt(C)
         if ops.fusable(dt, M, 4 * C, C):
             # data gradient of mlp_c_proj with the SwiGLU backward in the GEMM epilogue (dx_mlp never reaches HBM)
@@ -393,7 +395,7 @@ class _BlockFn(torch.autograd.Function):
         g_wp = rt.grad_buf((p_wp,), (C, 4 * C))
         rt.on_side(lambda: ops.gemm_tn(dy2_lo, xm, g_wp, M, C, 4 * C), dy2_lo, xm)
         g_bp = _bias_grad(dy2_lo, M, C) if ctx.has_b else None
-        d_suv = _param_grad_scaled(rt, part_suv, p_suv, 1.0)
+        d_suv = _param_grad_scaled(rt, part_suv, p_suv, 1.0, red)
         if lo_dgrad:
             dh1_add = ops.gemm_nt(duv, sh[pre + "fc.Wt"], M, C, 8 * C, out_dtype=td)   # bf16, added by the next lerp_bwd
         else:
@@ -409,7 +411,7 @@ class _BlockFn(torch.autograd.Function):
         else:
             dx, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dh1, x, y, attn_alpha, c_a, None, None, dx, True, False,
                                                         True, dout_add=dh1_add)
-        d_attn_alpha = _param_grad_alpha(rt, part_lam, p_aalpha, c_a)
+        d_attn_alpha = _param_grad_alpha(rt, part_lam, p_aalpha, c_a, red)
         do = ops.gemm_nt(dy_lo, sh[pre + "o.Wt"], M, C, C, out_dtype=td)
         g_wo = rt.grad_buf((p_wo,), (C, C))
         rt.on_side(lambda: ops.gemm_tn(dy_lo, o, g_wo, M, C, C), dy_lo, o)
@@ -419,13 +421,12 @@ class _BlockFn(torch.autograd.Function):
             # attention backward with the q/k-normalise backward fused into its epilogues
             part_q, part_k = ops.attn_bwd_qknorm(do, qh, kh, vh, o, lse, math.sqrt(d), rq, rk, sqk, c_q, dqkv, 3 * C,
                                                  dqkv[:, C:], dqkv[:, 2 * C:], 3 * C, q_prescale=ctx.qpre)
-            d_sqk = _param_grad_scaled(rt, part_q, p_sqk, c_q)
-            ops.colsum_reduce(part_k, d_sqk, True, kind=0, scale=c_q)
+            d_sqk = _param_grad_scaled(rt, part_q, p_sqk, c_q, red, part_b=part_k)
         else:
             dqh, dkh, dvh = ops.attn_bwd(dt, impl, do, qh, kh, vh, o, lse, math.sqrt(d))
             part_sqk = ops.qknorm_bwd(dt, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q, dqkv, 3 * C, dqkv[:, C:], 3 * C,
                                       dqkv[:, 2 * C:], 3 * C, B, T, H, d)
-            d_sqk = _param_grad_scaled(rt, part_sqk, p_sqk, c_q)
+            d_sqk = _param_grad_scaled(rt, part_sqk, p_sqk, c_q, red)
         if lo_dgrad and ctx.chained:
             # the consumer of dx is the backward node of the previous block (or of the cross-attention block): hand it
             # the q/k/v data gradient as a separate bf16 addend instead of read-modify-writing dx
@@ -435,6 +436,7 @@ class _BlockFn(torch.autograd.Function):
         g_qkv = rt.grad_buf((p_wq, p_wk, p_wv), (3 * C, C))   # one stacked GEMM output = three adjacent bucket slices
         rt.on_side(lambda: ops.gemm_tn(dqkv, x_lo, g_qkv, M, 3 * C, C), dqkv, x_lo)
         g_bqkv = _bias_grad(dqkv, M, 3 * C) if ctx.has_b else None
+        red.flush()
         rt.join()
         gq, gk, gv = g_qkv[:C], g_qkv[C:2 * C], g_qkv[2 * C:]
         if ctx.has_b:
@@ -517,10 +519,11 @@ class _CrossFn(torch.autograd.Function):
         dev = loc.device
         c_q, c_a = 1.0 / cfg.base_scale, 0.05 / cfg.base_scale
         dx = dx.contiguous()
+        red = ops.ReduceBatch()
         carry_in = _take_carry(rt, -1, ctx.chained, dx)
         dloc, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dx, loc, y, attn_alpha, c_a, None, None, None,
                                                       False, False, True, dout_add=carry_in)
-        d_alpha = _param_grad_alpha(rt, part_lam, p_alpha, c_a)
+        d_alpha = _param_grad_alpha(rt, part_lam, p_alpha, c_a, red)
         if ops.fusable(dt, M, C, C):
             dpr, _ = ops.gemm_nt_swiglu_bwd(dy_lo, sh["x.out.Wt"], pr, M, C, C, None, 1.0)
         else:
@@ -536,17 +539,17 @@ class _CrossFn(torch.autograd.Function):
         if impl == 1 and d == 64 and dt != F32:
             part_q, part_k = ops.attn_bwd_qknorm(do, qh, kh, vh, o, lse, math.sqrt(d), rq, rk, sqk, c_q, dq, C, dkv,
                                                  dkv[:, C:], 2 * C, q_prescale=ctx.qpre)
-            d_sqk = _param_grad_scaled(rt, part_q, p_sqk, c_q)
-            ops.colsum_reduce(part_k, d_sqk, True, kind=0, scale=c_q)
+            d_sqk = _param_grad_scaled(rt, part_q, p_sqk, c_q, red, part_b=part_k)
         else:
             dqh, dkh, dvh = ops.attn_bwd(dt, impl, do, qh, kh, vh, o, lse, math.sqrt(d))
             part_sqk = ops.qknorm_bwd(dt, dqh, dkh, dvh, qh, kh, rq, rk, sqk, c_q, dq, C, dkv, 2 * C, dkv[:, C:],
                                       2 * C, B, T, H, d)
-            d_sqk = _param_grad_scaled(rt, part_sqk, p_sqk, c_q)
+            d_sqk = _param_grad_scaled(rt, part_sqk, p_sqk, c_q, red)
         ops.gemm_nt(dq, sh["x.q.Wt"], M, C, C, out=dloc, accumulate=True)
         dglo = ops.gemm_nt(dkv, sh["x.kv.Wt"], M, C, 2 * C, out_dtype=torch.float32)
         g_wq = ops.gemm_tn(dq, loc_lo, rt.grad_buf((p_wq,), (C, C)), M, C, C)
         g_wkv = ops.gemm_tn(dkv, glo_lo, rt.grad_buf((p_wk, p_wv), (2 * C, C)), M, 2 * C, C)
+        red.flush()
         if ctx.has_b:
             g_bq = _bias_grad(dq, M, C)
             g_bkv = _bias_grad(dkv, M, 2 * C)

@@ -323,6 +323,42 @@ def colsum_reduce(part: Tensor, out: Tensor, accumulate: bool, kind: int = 0, re
           "nvit_colsum_reduce")
 
 
+class ReduceBatch:
+    """Column-partial reductions collected during one backward node and issued as ONE launch (`flush`): items are
+    (part [rows, N], out [N], accumulate, kind, ref, scale) as for `colsum_reduce`, optionally with a second partial
+    array that is reduced, scaled and added after the first (`part_b`)."""
+
+    def __init__(self) -> None:
+        self.items = []
+
+    def add(self, part: Tensor, out: Tensor, accumulate: bool = False, kind: int = 0, ref: Optional[Tensor] = None,
+            scale: float = 1.0, part_b: Optional[Tensor] = None) -> None:
+        self.items.append((part, out, accumulate, kind, ref, scale, part_b))
+        if len(self.items) == 8:
+            self.flush()
+
+    def flush(self) -> None:
+        items, self.items = self.items, []
+        n = len(items)
+        if n == 0:
+            return
+        if n == 1 and items[0][6] is None:
+            part, out, acc, kind, ref, scale, _ = items[0]
+            colsum_reduce(part, out, acc, kind, ref, scale)
+            return
+        I64, I32, F32_ = C.c_int64 * n, C.c_int * n, C.c_float * n
+        rows = lambda t: t.shape[0]
+        cols = lambda t: t.shape[1] if t.dim() == 2 else 1
+        check(_lib.load().nvit_colsum_reduce_multi(
+            I64(*[it[0].data_ptr() for it in items]), I32(*[rows(it[0]) for it in items]),
+            I64(*[(it[6].data_ptr() if it[6] is not None else 0) for it in items]),
+            I32(*[(rows(it[6]) if it[6] is not None else 0) for it in items]),
+            I32(*[cols(it[0]) for it in items]), I64(*[it[1].data_ptr() for it in items]),
+            I32(*[int(it[2]) for it in items]), I32(*[it[3] for it in items]),
+            I64(*[(it[4].data_ptr() if it[4] is not None else 0) for it in items]), F32_(*[float(it[5]) for it in items]),
+            n, _s()), "nvit_colsum_reduce_multi")
+
+
 def colsum(a: Tensor, R: int, N: int, out: Tensor, accumulate: bool, b: Optional[Tensor] = None, period: int = 0,
            scale: float = 1.0, lda: Optional[int] = None, ldb: Optional[int] = None) -> None:
     lda = a.stride(0) if lda is None else lda
