@@ -39,6 +39,29 @@ __device__ __forceinline__ float row_dot(const RowVec<NV>& a, const RowVec<NV>& 
   return wave_sum(s);
 }
 
+// Streaming variants (read-once inputs / write-once outputs of the backward row kernel): non-temporal accesses, switched
+// by NVIT_LERP_BWD_NT (experiments: 1 = loads, 2 = stores, 3 = both).
+#ifndef NVIT_LERP_BWD_NT
+#define NVIT_LERP_BWD_NT 1   // measured: loads -0.34 ms per Base step, stores +-0 (tools/ab_lib.sh)
+#endif
+template <int NV>
+__device__ __forceinline__ void row_load_f32_nt(RowVec<NV>& r, const float* p, int C, int lane) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if constexpr ((NVIT_LERP_BWD_NT & 1) != 0)
+      r.v[i] = c < C ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    else
+      r.v[i] = c < C ? load4<float>(p + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+}
+__device__ __forceinline__ void store4_f32_nt(float* p, f32x4 v) {
+  if constexpr ((NVIT_LERP_BWD_NT & 2) != 0)
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+  else
+    store4<float>(p, v);
+}
+
 // ------------------------------------------------------------------------------ LERP forward
 struct LerpFwdArgs {
   const float* h;
@@ -147,9 +170,9 @@ __global__ __launch_bounds__(256, (NV <= 3 ? NVIT_LERP_BWD_WAVES : 1)) void lerp
     uint2 ga[NV];                    // the bf16 addend stays packed until it is added (half the registers in flight)
     const size_t ro = (size_t)m * a.C;
     // every load of the row goes out before the first reduction: one memory round trip per row, not two or three
-    row_load<NV, float>(av, a.h + ro, a.C, lane);
+    row_load_f32_nt<NV>(av, a.h + ro, a.C, lane);
     row_load<NV, TY>(bv, reinterpret_cast<const TY*>(a.y) + ro, a.C, lane);
-    row_load<NV, float>(g, a.dout + ro, a.C, lane);
+    row_load_f32_nt<NV>(g, a.dout + ro, a.C, lane);
     if constexpr (ADD) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -157,7 +180,7 @@ __global__ __launch_bounds__(256, (NV <= 3 ? NVIT_LERP_BWD_WAVES : 1)) void lerp
         ga[i] = c < a.C ? *reinterpret_cast<const uint2*>(a.dout_add + ro + c) : make_uint2(0u, 0u);
       }
     }
-    if constexpr (SKIP) row_load<NV, float>(t, a.skip_x + ro, a.C, lane);
+    if constexpr (SKIP) row_load_f32_nt<NV>(t, a.skip_x + ro, a.C, lane);
     if constexpr (ADD) {   // incoming gradient = dout + dout_add: the GEMM that produced dout_add need not read-modify-write dout
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -231,7 +254,7 @@ __global__ __launch_bounds__(256, (NV <= 3 ? NVIT_LERP_BWD_WAVES : 1)) void lerp
       const f32x4 dy = (db - bv.v[i] * bdb) * rsy;
       if constexpr (ACCUM) dh += old.v[i];
       if (c < a.C) {
-        store4<float>(a.dh + ro + c, dh);
+        store4_f32_nt(a.dh + ro + c, dh);
         if (a.dy) store4<float>(a.dy + ro + c, dy);
         if (a.dy_lo) store4<TL>(reinterpret_cast<TL*>(a.dy_lo) + ro + c, dy);
       }
