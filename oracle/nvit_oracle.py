@@ -142,7 +142,7 @@ def attend(q: Tensor, k: Tensor, v: Tensor, s_eff: Tensor, H: int, lowp: LowP) -
         c2t = math.sqrt(d) * log2e
         qpre = c2t if C % 256 == 0 else 1.0           # fused q/k-normalise GEMM epilogue folds the factor into q's scale
         tb = c2t * s_eff.reshape(H, d).abs().max(dim=-1).values ** 2          # [H]
-        if float(tb.max()) <= 60.0:
+        if float(tb.detach().max()) <= 60.0:
             qs = lowp(nrm(heads(q, H)) * (s * qpre))
             z = _mm(qs, lowp(kh).transpose(-1, -2), lowp) * (c2t / qpre) - tb.reshape(1, H, 1, 1)
             pt = lowp(torch.exp2(z))
