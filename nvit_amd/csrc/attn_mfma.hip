@@ -28,13 +28,6 @@
 
 #include "common.h"
 
-#ifndef NVIT_DKV_PIPE
-#define NVIT_DKV_PIPE 1   // 1: every LDS read of a 32-query half up front; 2: + DMA issue spread over the tile (measured +-0)
-#endif
-#ifndef NVIT_DKV_AHEAD
-#define NVIT_DKV_AHEAD 2   // tiles the Q/dO ring runs ahead (ring slots = AHEAD + 1)
-#endif
-
 namespace {
 
 constexpr int D = 64;         // head dim
@@ -141,27 +134,24 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsign
 // 4 waves x 2 wave-instructions.  TILE_DMA = instructions per wave per tile.  `src`, row_base and nrows are wave
 // uniform; voff[i] = tile_voff(i, ...) are the lane's offsets inside a full tile, computed once per kernel.
 constexpr int TILE_DMA = 2;
-template <int NW = 4>
 __device__ __forceinline__ unsigned tile_voff(int i, unsigned ld_bytes, int lane, int wid) {
   const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
-  return (unsigned)((i * NW + wid) * 8 + r8) * ld_bytes + (unsigned)chunk * 16u;
+  return (unsigned)((i * 4 + wid) * 8 + r8) * ld_bytes + (unsigned)chunk * 16u;
 }
-// NW = waves of the workgroup (4 or 8): 8 / NW wave-instructions per wave per tile
-template <int NW = 4>
 __device__ __forceinline__ void tile_dma(const bf16* src, unsigned ld_bytes, int row_base, int nrows, unsigned tile_off,
-                                         int lane, int wid, const unsigned (&voff)[8 / NW]) {
+                                         int lane, int wid, const unsigned (&voff)[TILE_DMA]) {
   const char* sb = reinterpret_cast<const char*>(src) + (size_t)row_base * ld_bytes;
 #ifdef NVIT_PROBE_ATTN_NODMA   // timing probe: only the first tiles are really fetched
   if (row_base >= 2 * TKV) return;
 #endif
   if (row_base + TKV <= nrows) {
 #pragma unroll
-    for (int i = 0; i < 8 / NW; ++i) glds16s(sb, voff[i], tile_off + (i * NW + wid) * 1024);
+    for (int i = 0; i < TILE_DMA; ++i) glds16s(sb, voff[i], tile_off + (i * 4 + wid) * 1024);
   } else {   // ragged last tile: rows past the end re-read the last valid row (finite values, masked by the consumer)
     const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
 #pragma unroll
-    for (int i = 0; i < 8 / NW; ++i) {
-      const int grp = i * NW + wid;
+    for (int i = 0; i < TILE_DMA; ++i) {
+      const int grp = i * 4 + wid;
       int row = grp * 8 + r8;
       row = row_base + row < nrows ? row : nrows - 1 - row_base;
       glds16s(sb, (unsigned)row * ld_bytes + (unsigned)chunk * 16u, tile_off + grp * 1024);
@@ -174,7 +164,6 @@ __device__ __forceinline__ void tile_dma(const bf16* src, unsigned ld_bytes, int
 // i.e. every tile pays a full memory round trip (cdna_hip_programming.md, "mixing load KINDS in one k-loop").
 __device__ __forceinline__ void settle(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 __device__ __forceinline__ void settle(float& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void settle(f32x4& v) { asm volatile("" : "+v"(v)); }
 
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(uintptr_t)((__attribute__((address_space(3))) void*)p);
@@ -192,19 +181,6 @@ __device__ __forceinline__ void work_of(int ntile, int& bh, int& tile) {
   tile = w - bh * ntile;
 }
 
-#ifdef NVIT_PROBE_ATTN_STAMPS   // diagnostic build only (tools/attn_variant.sh without NVIT_PRODUCT_BUILD): in-kernel cycle stamps
-__device__ unsigned long long nvit_attn_stamp_acc[16];
-#define NVIT_STAMP_DECL unsigned long long st_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, st_prev = 0
-#define NVIT_STAMP_START() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); st_prev = __builtin_amdgcn_s_memtime(); }
-#define NVIT_STAMP(i_) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i_] += n_ - st_prev; st_prev = n_; }
-#define NVIT_STAMP_FLUSH(cond_) if ((cond_) && (threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 9; ++i_) atomicAdd(&nvit_attn_stamp_acc[i_], st_acc[i_]); atomicAdd(&nvit_attn_stamp_acc[15], 1ull); }
-#else
-#define NVIT_STAMP_DECL
-#define NVIT_STAMP_START()
-#define NVIT_STAMP(i_)
-#define NVIT_STAMP_FLUSH(cond_)
-#endif
-
 // ------------------------------------------------------------------------------------------ forward
 // `sqk` != NULL (nViT call sites): q and k are s * unit vectors with s = sqk*c_q per channel, so every score obeys
 // |q.k| <= smax^2 (smax = max_d |s_d| of the head).  When that bound is small enough that exp2 cannot underflow
@@ -216,8 +192,7 @@ __device__ unsigned long long nvit_attn_stamp_acc[16];
 // softmax below runs.
 constexpr float BOUND_MAX = 60.0f;   // in log2 units: exp2(-2*60) is still a normal fp32 / bf16 number
 
-template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_fwd_mfma_kernel(const bf16* __restrict__ qh, const bf16* __restrict__ kh,
+__global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __restrict__ qh, const bf16* __restrict__ kh,
                                                              const bf16* __restrict__ vh, float scale, float qpre,
                                                              const float* __restrict__ sqk, float c_q,
                                                              bf16* __restrict__ o, float* __restrict__ lse, int H,
@@ -226,9 +201,9 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_fwd_mfma_kernel
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   int bh, tile_;
-  work_of((Tq + 32 * NW - 1) / (32 * NW), bh, tile_);
+  work_of((Tq + 127) / 128, bh, tile_);
   const int b = bh / H, h = bh % H;
-  const int q0 = tile_ * (32 * NW) + wid * 32;
+  const int q0 = tile_ * 128 + wid * 32;
   const bf16* kbase = kh + (size_t)bh * Tk * D;
   const bf16* vbase = vh + (size_t)bh * Tk * D;
   // qh holds qpre * q_hat (the producer folds the factor into the learned scale, one rounding): the MFMA result times
@@ -260,14 +235,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_fwd_mfma_kernel
   const int nt = (Tk + TKV - 1) / TKV;
   // K/V ring: LDS-DMA two tiles ahead, counted vmcnt (4 younger DMA instructions may stay in flight)
   const unsigned ring = lds_addr(&lds[0][0][0]);
-  unsigned voff[8 / NW];
-#pragma unroll
-  for (int i = 0; i < 8 / NW; ++i) voff[i] = tile_voff<NW>(i, ROWB, lane, wid);
-  tile_dma<NW>(kbase, ROWB, 0, Tk, ring, lane, wid, voff);
-  tile_dma<NW>(vbase, ROWB, 0, Tk, ring + TILE_BYTES, lane, wid, voff);
+  const unsigned voff[TILE_DMA] = {tile_voff(0, ROWB, lane, wid), tile_voff(1, ROWB, lane, wid)};
+  tile_dma(kbase, ROWB, 0, Tk, ring, lane, wid, voff);
+  tile_dma(vbase, ROWB, 0, Tk, ring + TILE_BYTES, lane, wid, voff);
   if (nt > 1) {
-    tile_dma<NW>(kbase, ROWB, TKV, Tk, ring + 2 * TILE_BYTES, lane, wid, voff);
-    tile_dma<NW>(vbase, ROWB, TKV, Tk, ring + 3 * TILE_BYTES, lane, wid, voff);
+    tile_dma(kbase, ROWB, TKV, Tk, ring + 2 * TILE_BYTES, lane, wid, voff);
+    tile_dma(vbase, ROWB, TKV, Tk, ring + 3 * TILE_BYTES, lane, wid, voff);
   }
   // the wave's own Q rows: requested AFTER the DMA (one memory round trip for everything) and settled before the loop
 #pragma unroll
@@ -297,8 +270,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_fwd_mfma_kernel
     constexpr bool UNIT = decltype(unit_)::value;
     if (t + 2 < nt) {
       const int sl = cur == 0 ? 2 : cur - 1;  // (t + 2) % 3
-      tile_dma<NW>(kbase, ROWB, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid, voff);
-      tile_dma<NW>(vbase, ROWB, (t + 2) * TKV, Tk, ring + (2 * sl + 1) * TILE_BYTES, lane, wid, voff);
+      tile_dma(kbase, ROWB, (t + 2) * TKV, Tk, ring + (2 * sl) * TILE_BYTES, lane, wid, voff);
+      tile_dma(vbase, ROWB, (t + 2) * TKV, Tk, ring + (2 * sl + 1) * TILE_BYTES, lane, wid, voff);
     }
     if (wave_active && FAST) {
       const char* kt = &lds[cur][0][0];
@@ -424,7 +397,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void attn_fwd_mfma_kernel
           }
     }
     if (t + 2 < nt)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (8 / NW)) : "memory");
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -753,13 +726,7 @@ __device__ __forceinline__ void glds4a(const void* gsrc, unsigned lds_off) {
 // -delta enters as the initial accumulator of the dP product, the softmax scale is applied once to the dK accumulators,
 // and P / dS are packed to bf16 as soon as a 16-query fragment is done, so only packed halves stay live.
 constexpr int DKV_SLOT = 2 * TILE_BYTES + 512;     // Q tile | dO tile | lse[64] | delta[64]
-#if defined(NVIT_PROBE_ATTN_NOQ) || defined(NVIT_PROBE_ATTN_NODO)
-constexpr int DKV_DMA = TILE_DMA + 2;
-#elif defined(NVIT_PROBE_ATTN_NOSIDE)
-constexpr int DKV_DMA = 2 * TILE_DMA;
-#else
-constexpr int DKV_DMA = 2 * TILE_DMA + 2;          // DMA wave-instructions per wave per tile
-#endif
+constexpr int DKV_DMA = 2 * TILE_DMA + 2;          // DMA wave-instructions per wave per tile 
 constexpr int DKV_WAVES = 2;   // waves per SIMD the register budget is sized for (222 VGPRs; at 3 the kernel spills 118)
 
 template <bool FUSE>
@@ -770,8 +737,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
                                                                  float qpre, bf16* __restrict__ dkh,
                                                                  bf16* __restrict__ dvh, int H, int Tq, int Tk,
                                                                  QkFuse fu) {
-  constexpr int AH = NVIT_DKV_AHEAD, NS = AH + 1;
-  __shared__ __attribute__((aligned(16))) char lds[NS * DKV_SLOT];
+  __shared__ __attribute__((aligned(16))) char lds[3 * DKV_SLOT];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lg = lane >> 4;
@@ -781,7 +747,7 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
   const int k0 = tile_ * 128 + wid * 32;
   const bf16* qbase = qh + (size_t)bh * Tq * D;
   const bf16* gbase = dout + (size_t)b * Tq * (H * D) + h * D;
-  const float* dbase = delta + (size_t)bh * Tq;
+  const float* dbase = delta + (size_t)bh * Tq;                                   // -delta, written by the dq kernel
   const float* lbase = delta + ((size_t)(gridDim.x / ((Tk + 127) / 128)) + bh) * Tq;   // -lse * log2(e), written by the dq kernel
   const float c2 = scale * LOG2E / qpre;   // see the forward kernel
   const bool unit = __builtin_amdgcn_readfirstlane(fabsf(c2 - 1.0f) < 1e-6f ? 1 : 0) != 0;
@@ -793,35 +759,15 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
   const unsigned voff_g[TILE_DMA] = {tile_voff(0, ldg_bytes, lane, wid), tile_voff(1, ldg_bytes, lane, wid)};
   auto tile_issue = [&](int t, int slot) {
     const unsigned so = ring + (unsigned)slot * DKV_SLOT;
-#ifndef NVIT_PROBE_ATTN_NOQ
     tile_dma(qbase, ROWB, t * TKV, Tq, so, lane, wid, voff_q);
-#endif
-#ifndef NVIT_PROBE_ATTN_NODO
     tile_dma(gbase, ldg_bytes, t * TKV, Tq, so + TILE_BYTES, lane, wid, voff_g);
-#endif
     int q = t * TKV + lane;
     q = q < Tq ? q : Tq - 1;
-#ifndef NVIT_PROBE_ATTN_NOSIDE
     glds4a(lbase + q, so + 2 * TILE_BYTES);        // every wave writes the same 256 bytes (keeps vmcnt uniform)
     glds4a(dbase + q, so + 2 * TILE_BYTES + 256);
-#endif
-  };
-  // the same six DMA instructions one at a time (full tiles only): issued in a burst they fill the CU's vector-memory
-  // queue and the issuing wave sits blocked at the next one instead of computing; spread over the tile body they drain
-  auto tile_issue_piece = [&](int t, int slot, int piece) {
-    const unsigned so = ring + (unsigned)slot * DKV_SLOT;
-    if (piece < 2) {
-      glds16s(reinterpret_cast<const char*>(qbase) + (size_t)(t * TKV) * ROWB, voff_q[piece], so + (piece * 4 + wid) * 1024);
-    } else if (piece < 4) {
-      glds16s(reinterpret_cast<const char*>(gbase) + (size_t)(t * TKV) * ldg_bytes, voff_g[piece - 2],
-              so + TILE_BYTES + ((piece - 2) * 4 + wid) * 1024);
-    } else {
-      glds4a((piece == 4 ? lbase : dbase) + t * TKV + lane, so + 2 * TILE_BYTES + (piece - 4) * 256);
-    }
   };
   tile_issue(0, 0);
   if (nt > 1) tile_issue(1, 1);
-  if (AH > 2 && nt > 2) tile_issue(2, 2);
 
   uint4 kf_[2][2], vf_[2][2];  // [key frag][ks]: K / V rows of this wave's 32 keys (MFMA-B operands)
 #pragma unroll
@@ -854,26 +800,21 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
     }
   const bool wave_active = k0 < Tk;   // a wave whose 32 keys all lie past Tk only feeds the ring and the barriers
   int cur = 0;
-  NVIT_STAMP_DECL;
   auto tile_body = [&](const int t, auto masked_, auto unit_) {
     constexpr bool MASKED = decltype(masked_)::value;
     constexpr bool UNIT = decltype(unit_)::value;
-    NVIT_STAMP_START();
-    const int nslot = cur == 0 ? NS - 1 : cur - 1;   // slot of tile t-1 = slot of tile t+AH
-    // spread: tile t+AH is a full tile and this wave runs the pipelined body below (which carries the issue points)
-    const bool spread = NVIT_DKV_PIPE == 2 && !MASKED && wave_active && (t + AH + 1) * TKV <= Tq;
-    if (t + AH < nt && !spread) tile_issue(t + AH, nslot);
-    NVIT_STAMP(0);
+    if (t + 2 < nt) tile_issue(t + 2, cur == 0 ? 2 : cur - 1);
     if (wave_active) {
       const char* qt = &lds[cur * DKV_SLOT];
       const char* gt = qt + TILE_BYTES;
       const float* st = reinterpret_cast<const float*>(qt + 2 * TILE_BYTES);
       const int nvalid = MASKED ? Tq - t * TKV : TKV;   // queries of this tile that exist
       const int nqf = MASKED ? (nvalid + 15) >> 4 : 4, ns2 = MASKED ? (nvalid + 31) >> 5 : 2;
-#if NVIT_DKV_PIPE
       if constexpr (!MASKED) {
-        // full tiles: every LDS read of a 32-query half is issued before its first MFMA (the compiler otherwise issues
-        // each fragment group just in time and exposes the LDS latency eight times per tile)
+        // Full tiles: every LDS read of a 32-query half (row fragments of Q and dO, -lse, -delta, transposed fragments) is
+        // issued before its first MFMA, the four accumulator chains of a query fragment are interleaved, and the region
+        // is fenced - hipcc otherwise issues each fragment group just in time and waits for the LDS eight times per tile
+        // (245 instead of 286 instructions per tile, 6 instead of 28 lgkmcnt waits).
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           uint4 a[2][2], gg[2][2], ga[4], qa[4];
@@ -883,31 +824,28 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
             const int qfi = 2 * s2 + qq;
             a[qq][0] = row_frag(qt, qfi * 16, 0, l15, lg), a[qq][1] = row_frag(qt, qfi * 16, 1, l15, lg);
             gg[qq][0] = row_frag(gt, qfi * 16, 0, l15, lg), gg[qq][1] = row_frag(gt, qfi * 16, 1, l15, lg);
-            nl[qq] = *reinterpret_cast<const f32x4*>(st + qfi * 16 + 4 * lg);
-            nd[qq] = *reinterpret_cast<const f32x4*>(st + 64 + qfi * 16 + 4 * lg);
+            nl[qq] = *reinterpret_cast<const f32x4*>(st + qfi * 16 + 4 * lg);        // -lse (log2 units) of the 4 queries
+            nd[qq] = *reinterpret_cast<const f32x4*>(st + 64 + qfi * 16 + 4 * lg);   // -delta
           }
 #pragma unroll
           for (int df = 0; df < 4; ++df) {
-            ga[df] = tr_frag(gt, s2 * 32, df * 16, l15, lg);
-            qa[df] = tr_frag(qt, s2 * 32, df * 16, l15, lg);
+            ga[df] = tr_frag(gt, s2 * 32, df * 16, l15, lg);   // dO^T[d][q slots]
+            qa[df] = tr_frag(qt, s2 * 32, df * 16, l15, lg);   // Q^T[d][q slots]
           }
           __builtin_amdgcn_sched_barrier(0);
-          if (spread) tile_issue_piece(t + AH, nslot, 3 * s2);
-          __builtin_amdgcn_sched_barrier(0);
-          NVIT_STAMP(1 + 3 * s2);
-          uint2 ph[2][2], sh[2][2];
+          uint2 ph[2][2], sh[2][2];   // [qq][key frag] packed bf16 P / dS of query frag 2*s2 + qq
 #pragma unroll
           for (int qq = 0; qq < 2; ++qq) {
             f32x4 z[2], w[2];
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
               z[f] = mfma16(a[qq][0], kf_[f][0], UNIT ? nl[qq] : (f32x4){0.f, 0.f, 0.f, 0.f});
-              w[f] = mfma16(gg[qq][0], vf_[f][0], nd[qq]);
+              w[f] = mfma16(gg[qq][0], vf_[f][0], nd[qq]);   // row constants -delta as the initial accumulator
             }
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
-              z[f] = mfma16(a[qq][1], kf_[f][1], z[f]);
-              w[f] = mfma16(gg[qq][1], vf_[f][1], w[f]);
+              z[f] = mfma16(a[qq][1], kf_[f][1], z[f]);    // S[q][key] (UNIT: already minus lse, in log2 units)
+              w[f] = mfma16(gg[qq][1], vf_[f][1], w[f]);   // dP[q][key] - delta[q]
             }
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
@@ -927,17 +865,6 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
             pb[f] = make_uint4(ph[0][f].x, ph[0][f].y, ph[1][f].x, ph[1][f].y);
             sb[f] = make_uint4(sh[0][f].x, sh[0][f].y, sh[1][f].x, sh[1][f].y);
           }
-#if NVIT_DKV_PIPE == 2
-          settle(pb[0]); settle(pb[1]); settle(sb[0]); settle(sb[1]);
-          __builtin_amdgcn_sched_barrier(0);
-          if (spread) tile_issue_piece(t + AH, nslot, 3 * s2 + 1);
-          __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifdef NVIT_PROBE_ATTN_STAMPS
-          settle(pb[0]); settle(pb[1]); settle(sb[0]); settle(sb[1]);
-          __builtin_amdgcn_sched_barrier(0);
-          NVIT_STAMP(2 + 3 * s2);
-#endif
 #pragma unroll
           for (int df = 0; df < 4; ++df)
 #pragma unroll
@@ -946,18 +873,11 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
               dk[df][f] = mfma16(qa[df], sb[f], dk[df][f]);
             }
           __builtin_amdgcn_sched_barrier(0);
-          if (spread) tile_issue_piece(t + AH, nslot, 3 * s2 + 2);
-          __builtin_amdgcn_sched_barrier(0);
-#ifdef NVIT_PROBE_ATTN_STAMPS
-          settle(dv[3][1]); settle(dk[3][1]);
-          NVIT_STAMP(3 + 3 * s2);
-#endif
         }
       } else
-#endif
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
-        if (MASKED && s2 >= ns2) continue;
+        if (s2 >= ns2) continue;
         uint2 ph[2][2], sh[2][2];  // [qq][key frag] packed bf16 P / dS of query frag qfi = 2*s2 + qq (rows 16qfi + 4lg + r)
 #pragma unroll
         for (int qq = 0; qq < 2; ++qq) {
@@ -1009,17 +929,12 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
         }
       }
     }
-    // tile t+1 must have landed; the AH-1 tiles behind it may stay in flight
-    if (t + AH < nt)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AH - 1) * DKV_DMA) : "memory");
-    else if (AH > 2 && t + 2 < nt)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((AH - 2) * DKV_DMA) : "memory");
+    if (t + 2 < nt)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DKV_DMA) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    NVIT_STAMP(7);
     __syncthreads();
-    NVIT_STAMP(8);
-    cur = cur == NS - 1 ? 0 : cur + 1;
+    cur = cur == 2 ? 0 : cur + 1;
   };
 #define NVIT_RUN_TILES(UNIT_)                                                          \
   {                                                                                    \
@@ -1034,7 +949,6 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
   else
     NVIT_RUN_TILES(std::false_type)
 #undef NVIT_RUN_TILES
-  NVIT_STAMP_FLUSH(wave_active);
   const float dks = scale / qpre;   // d/d(k_hat) = scale * dS^T q_hat, and the Q tiles hold qpre * q_hat
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1061,16 +975,9 @@ int nvit_attn_fwd_mfma(const void* qh, const void* kh, const void* vh, float sca
                        float c_q, void* o, float* lse, int B, int H, int Tq, int Tk, int d, hipStream_t s) {
   NVIT_REQUIRE(d == 64, "attn_fwd: the MFMA kernel supports head dim 64 only (got %d)", d);
   NVIT_REQUIRE(qpre > 0.f, "attn_fwd: the q pre-scale must be positive (got %g)", (double)qpre);
-  static const int nw = getenv("NVIT_ATTN_FWD_NW") ? atoi(getenv("NVIT_ATTN_FWD_NW")) : 4;   // EXPERIMENT
-  if (nw == 8) {
-    dim3 grid((unsigned)(cdiv(Tq, 256) * B * H));
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel<8>, grid, dim3(512), 0, s, (const bf16*)qh, (const bf16*)kh, (const bf16*)vh,
-                       scale, qpre, sqk, c_q, (bf16*)o, lse, H, Tq, Tk);
-  } else {
-    dim3 grid((unsigned)(cdiv(Tq, 128) * B * H));
-    hipLaunchKernelGGL(attn_fwd_mfma_kernel<4>, grid, dim3(256), 0, s, (const bf16*)qh, (const bf16*)kh, (const bf16*)vh,
-                       scale, qpre, sqk, c_q, (bf16*)o, lse, H, Tq, Tk);
-  }
+  dim3 grid((unsigned)(cdiv(Tq, 128) * B * H));
+  hipLaunchKernelGGL(attn_fwd_mfma_kernel, grid, dim3(256), 0, s, (const bf16*)qh, (const bf16*)kh, (const bf16*)vh,
+                     scale, qpre, sqk, c_q, (bf16*)o, lse, H, Tq, Tk);
   NVIT_CHECK_LAUNCH("attn_fwd_mfma");
   return NVIT_OK;
 }
@@ -1106,32 +1013,13 @@ int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, c
   NVIT_REQUIRE(qpre > 0.f, "attn_bwd: the q pre-scale must be positive (got %g)", (double)qpre);
   QkFuse fq{rq, sqk, c_q, (bf16*)dq, nullptr, ldq, part_q, 1.0f / qpre};
   QkFuse fk{rk, sqk, c_q, (bf16*)dk, (bf16*)dv, ldkv, part_k, 1.0f};
-  static int pad = -1;   // EXPERIMENT: extra dynamic LDS to lower the occupancy
-  if (pad < 0) {
-    pad = getenv("NVIT_ATTN_LDS_PAD") ? atoi(getenv("NVIT_ATTN_LDS_PAD")) : 0;
-    if (pad) {
-      hipFuncSetAttribute((const void*)attn_bwd_dq_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-      hipFuncSetAttribute((const void*)attn_bwd_dkv_mfma_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-    }
-  }
-  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, gq, dim3(256), pad, s, (const bf16*)dout, (const bf16*)qh,
+  hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, gq, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
                      (const bf16*)kh, (const bf16*)vh, lse, (const bf16*)o, delta, scale, qpre, (bf16*)nullptr, H, Tq, Tk,
                      fq);
   NVIT_CHECK_LAUNCH("attn_bwd_dq_mfma_fused");
-  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, gk, dim3(256), pad, s, (const bf16*)dout, (const bf16*)qh,
+  hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
                      (const bf16*)kh, (const bf16*)vh, lse, delta, scale, qpre, (bf16*)nullptr, (bf16*)nullptr, H, Tq,
                      Tk, fk);
   NVIT_CHECK_LAUNCH("attn_bwd_dkv_mfma_fused");
   return NVIT_OK;
 }
-
-#ifdef NVIT_PROBE_ATTN_STAMPS
-extern "C" int nvit_attn_stamps_read(unsigned long long* out16, int reset) {
-  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(nvit_attn_stamp_acc), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
-  if (reset) {
-    unsigned long long z[16] = {};
-    if (hipMemcpyToSymbol(HIP_SYMBOL(nvit_attn_stamp_acc), z, sizeof(z)) != hipSuccess) return 1;
-  }
-  return 0;
-}
-#endif
