@@ -258,7 +258,7 @@ int nvit_attn_fwd(int dt, int impl, const void* qh, const void* kh, const void* 
 int nvit_attn_fwd_bounded(int dt, int impl, const void* qh, const void* kh, const void* vh, float scale, const float* sqk,
                           float c_q, float q_prescale, void* o, float* lse, int B, int H, int Tq, int Tk, int d,
                           void* stream);
-/* delta: [2,B,H,Tq] fp32 workspace (rowsum(dO*O), and MINUS lse in log2 units - an accumulator seed of the dk/dv
+/* delta: [2,B,H,Tq] fp32 workspace (MINUS rowsum(dO*O) and MINUS lse in log2 units - accumulator seeds of the dk/dv
  * kernel). dqh,dkh,dvh [B,H,T,d] type dt. */
 int nvit_attn_bwd(int dt, int impl, const void* dout, const void* qh, const void* kh, const void* vh, const void* o,
                   const float* lse, float scale, void* dqh, void* dkh, void* dvh, float* delta, int B, int H,

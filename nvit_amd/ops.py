@@ -435,7 +435,7 @@ def attn_bwd(dt: int, impl: int, dout: Tensor, qh: Tensor, kh: Tensor, vh: Tenso
     dqh = torch.empty_like(qh)
     dkh = torch.empty_like(kh)
     dvh = torch.empty_like(vh)
-    delta = torch.empty((2, B, H, Tq), device=qh.device, dtype=torch.float32)   # delta | lse*log2(e)
+    delta = torch.empty((2, B, H, Tq), device=qh.device, dtype=torch.float32)   # workspace: -delta | -lse*log2(e)
     check(_lib.load().nvit_attn_bwd(dt, impl, _p(dout), _p(qh), _p(kh), _p(vh), _p(o), _p(lse), scale, _p(dqh),
                                     _p(dkh), _p(dvh), _p(delta), B, H, Tq, Tk, d, _s()), "nvit_attn_bwd")
     return dqh, dkh, dvh
@@ -451,7 +451,7 @@ def attn_bwd_qknorm(dout: Tensor, qh: Tensor, kh: Tensor, vh: Tensor, o: Tensor,
     dev = qh.device
     part_q = torch.empty((B * math.ceil(Tq / 128), H * d), device=dev, dtype=torch.float32)
     part_k = torch.empty((B * math.ceil(Tk / 128), H * d), device=dev, dtype=torch.float32)
-    delta = torch.empty((2, B, H, Tq), device=dev, dtype=torch.float32)   # delta | -lse*log2(e)
+    delta = torch.empty((2, B, H, Tq), device=dev, dtype=torch.float32)   # workspace: -delta | -lse*log2(e)
     check(_lib.load().nvit_attn_bwd_qknorm(BF16, _p(dout), _p(qh), _p(kh), _p(vh), _p(o), _p(lse), scale, _p(rq),
                                            _p(rk), _p(sqk), c_q, q_prescale, _p(dq), ldq, _p(dk), _p(dv), ldkv, _p(part_q),
                                            _p(part_k), _p(delta), B, H, Tq, Tk, d, _s()), "nvit_attn_bwd_qknorm")
