@@ -160,6 +160,12 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
     if (probe_issued++ < NSLOT)
 #endif
     {
+#ifdef NVIT_PROBE_DOUBLE_DMA   // (probe: every DMA instruction issued twice - same bytes, same place: what does the ISSUE cost?)
+#pragma unroll
+      for (int i = 0; i < Cfg::A_DMA; ++i) glds16(ap[i] + ko, bo + i * 8192);
+#pragma unroll
+      for (int i = 0; i < Cfg::B_DMA; ++i) glds16(bp[i] + ko, bo + A_BYTES + i * 8192);
+#endif
 #pragma unroll
       for (int i = 0; i < Cfg::A_DMA; ++i) glds16(ap[i] + ko, bo + i * 8192);
 #ifdef NVIT_PROBE_NO_B_DMA   // (probe: the B operand is fetched only for the first stages - half the LDS-DMA writes)
