@@ -134,6 +134,11 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsign
 // 4 waves x 2 wave-instructions.  TILE_DMA = instructions per wave per tile.  `src`, row_base and nrows are wave
 // uniform; voff[i] = tile_voff(i, ...) are the lane's offsets inside a full tile, computed once per kernel.
 constexpr int TILE_DMA = 2;
+#ifdef NVIT_PROBE_ATTN_DOUBLE_DMA   // timing probe: every tile DMA instruction issued twice (same bytes, same place)
+constexpr int DMA_REP = 2;
+#else
+constexpr int DMA_REP = 1;
+#endif
 __device__ __forceinline__ unsigned tile_voff(int i, unsigned ld_bytes, int lane, int wid) {
   const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
   return (unsigned)((i * 4 + wid) * 8 + r8) * ld_bytes + (unsigned)chunk * 16u;
@@ -146,6 +151,8 @@ __device__ __forceinline__ void tile_dma(const bf16* src, unsigned ld_bytes, int
 #endif
   if (row_base + TKV <= nrows) {
 #pragma unroll
+    for (int rep = 0; rep < DMA_REP; ++rep)
+#pragma unroll
     for (int i = 0; i < TILE_DMA; ++i) glds16s(sb, voff[i], tile_off + (i * 4 + wid) * 1024);
   } else {   // ragged last tile: rows past the end re-read the last valid row (finite values, masked by the consumer)
     const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
@@ -154,6 +161,8 @@ __device__ __forceinline__ void tile_dma(const bf16* src, unsigned ld_bytes, int
       const int grp = i * 4 + wid;
       int row = grp * 8 + r8;
       row = row_base + row < nrows ? row : nrows - 1 - row_base;
+#pragma unroll
+      for (int rep = 0; rep < DMA_REP; ++rep)
       glds16s(sb, (unsigned)row * ld_bytes + (unsigned)chunk * 16u, tile_off + grp * 1024);
     }
   }
@@ -397,7 +406,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
           }
     }
     if (t + 2 < nt)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DMA_REP) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
           }
     }
     if (t + 2 < nt)
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DMA_REP) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -726,7 +735,7 @@ __device__ __forceinline__ void glds4a(const void* gsrc, unsigned lds_off) {
 // -delta enters as the initial accumulator of the dP product, the softmax scale is applied once to the dK accumulators,
 // and P / dS are packed to bf16 as soon as a 16-query fragment is done, so only packed halves stay live.
 constexpr int DKV_SLOT = 2 * TILE_BYTES + 512;     // Q tile | dO tile | lse[64] | delta[64]
-constexpr int DKV_DMA = 2 * TILE_DMA + 2;          // DMA wave-instructions per wave per tile 
+constexpr int DKV_DMA = 2 * TILE_DMA * DMA_REP + 2;          // DMA wave-instructions per wave per tile 
 constexpr int DKV_WAVES = 2;   // waves per SIMD the register budget is sized for (222 VGPRs; at 3 the kernel spills 118)
 
 template <bool FUSE>
