@@ -41,11 +41,7 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // raw v_exp_f32 (no denormal range fix-up: arguments here are <= 0 after max subtraction, or bounded
 // by the saved log-sum-exp in the backward kernels; results below 2^-126 flush to 0, which is the
 // correct limit for a softmax weight)
-#ifdef NVIT_PROBE_ATTN_NOEXP    // timing probe: the exponential replaced by one multiply
-__device__ __forceinline__ float fast_exp2(float x) { return x * 0.001f; }
-#else
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-#endif
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * ROWB + ((chunk ^ (row & 7)) << 4); }
 
@@ -56,9 +52,6 @@ __device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, f32x4 c)
 // transposed fragment: element j<4 = tile[row0 + 4*lg + j][col0 + l15], j>=4 = tile[row0 + 16 + 4*lg + (j-4)][..]
 // (the k-slot order matching accumulators of two adjacent 16-row MFMA tiles used as the other operand)
 __device__ __forceinline__ uint4 tr_frag(const char* tile, int row0, int col0, int l15, int lg) {
-#ifdef NVIT_PROBE_ATTN_NOLDS
-  return make_uint4(0x3c003c00u + row0, 0x3c003c00u + col0, 0x3c003c00u + l15, 0x3c003c00u + lg);
-#endif
   const int q = l15 >> 2, p = l15 & 3;
   const int r0 = row0 + 4 * lg + q, r1 = r0 + 16;
   const int ch = (col0 >> 3) + (p >> 1);
@@ -71,11 +64,7 @@ __device__ __forceinline__ uint4 tr_frag(const char* tile, int row0, int col0, i
 
 // row fragment: tile[row0 + l15][32*ks + 8*lg .. +7]
 __device__ __forceinline__ uint4 row_frag(const char* tile, int row0, int ks, int l15, int lg) {
-#ifdef NVIT_PROBE_ATTN_NOLDS   // timing probe (tools/probes/attn_parts.sh): fragments without LDS traffic, results are garbage
-  return make_uint4(0x3c003c00u + row0, 0x3c003c00u + ks, 0x3c003c00u + l15, 0x3c003c00u + lg);
-#else
   return *reinterpret_cast<const uint4*>(tile + swz_off(row0 + l15, ks * 4 + lg));
-#endif
 }
 
 __device__ __forceinline__ uint4 pack8(const f32x4& a, const f32x4& b) {
@@ -134,11 +123,7 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsign
 // 4 waves x 2 wave-instructions.  TILE_DMA = instructions per wave per tile.  `src`, row_base and nrows are wave
 // uniform; voff[i] = tile_voff(i, ...) are the lane's offsets inside a full tile, computed once per kernel.
 constexpr int TILE_DMA = 2;
-#ifdef NVIT_PROBE_ATTN_DOUBLE_DMA   // timing probe: every tile DMA instruction issued twice (same bytes, same place)
-constexpr int DMA_REP = 2;
-#else
 constexpr int DMA_REP = 1;
-#endif
 __device__ __forceinline__ unsigned tile_voff(int i, unsigned ld_bytes, int lane, int wid) {
   const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
   return (unsigned)((i * 4 + wid) * 8 + r8) * ld_bytes + (unsigned)chunk * 16u;
@@ -146,9 +131,6 @@ __device__ __forceinline__ unsigned tile_voff(int i, unsigned ld_bytes, int lane
 __device__ __forceinline__ void tile_dma(const bf16* src, unsigned ld_bytes, int row_base, int nrows, unsigned tile_off,
                                          int lane, int wid, const unsigned (&voff)[TILE_DMA]) {
   const char* sb = reinterpret_cast<const char*>(src) + (size_t)row_base * ld_bytes;
-#ifdef NVIT_PROBE_ATTN_NODMA   // timing probe: only the first tiles are really fetched
-  if (row_base >= 2 * TKV) return;
-#endif
   if (row_base + TKV <= nrows) {
 #pragma unroll
     for (int rep = 0; rep < DMA_REP; ++rep)

@@ -77,11 +77,7 @@ __device__ __forceinline__ uint4 ld16_nt(const void* p) {
 }
 __device__ __forceinline__ void st16_nt(void* p, const uint4& v) {
   typedef unsigned int u32x4_ __attribute__((ext_vector_type(4)));
-#ifdef NVIT_PROBE_PLAIN_STORE
-  *reinterpret_cast<u32x4_*>(p) = __builtin_bit_cast(u32x4_, v);   // tools/probes/gemm_parts.hip
-#else
   __builtin_nontemporal_store(__builtin_bit_cast(u32x4_, v), reinterpret_cast<u32x4_*>(p));
-#endif
 }
 
 

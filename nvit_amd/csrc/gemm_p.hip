@@ -147,30 +147,12 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
       bp[i] = g.B + ((size_t)rb * g.ldb + (size_t)gc * EPC) * sizeof(T);
     }
   };
-#ifdef NVIT_PROBE_NO_DMA
-  int probe_issued = 0;   // tools/probes/gemm_parts.hip: only the first NSLOT stages are really fetched
-#endif
-#ifdef NVIT_PROBE_NO_B_DMA
-  int probe_b = 0;
-#endif
   auto issue_stage = [&]() {
     const unsigned bo = lds_base + wave_off + (unsigned)l_slot * SLOT_BYTES;
     const size_t ko = (size_t)l_k * ROWB;
-#ifdef NVIT_PROBE_NO_DMA
-    if (probe_issued++ < NSLOT)
-#endif
     {
-#ifdef NVIT_PROBE_DOUBLE_DMA   // (probe: every DMA instruction issued twice - same bytes, same place: what does the ISSUE cost?)
 #pragma unroll
       for (int i = 0; i < Cfg::A_DMA; ++i) glds16(ap[i] + ko, bo + i * 8192);
-#pragma unroll
-      for (int i = 0; i < Cfg::B_DMA; ++i) glds16(bp[i] + ko, bo + A_BYTES + i * 8192);
-#endif
-#pragma unroll
-      for (int i = 0; i < Cfg::A_DMA; ++i) glds16(ap[i] + ko, bo + i * 8192);
-#ifdef NVIT_PROBE_NO_B_DMA   // (probe: the B operand is fetched only for the first stages - half the LDS-DMA writes)
-      if (probe_b++ < NSLOT)
-#endif
 #pragma unroll
       for (int i = 0; i < Cfg::B_DMA; ++i) glds16(bp[i] + ko, bo + A_BYTES + i * 8192);
     }
@@ -241,7 +223,6 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
     // a stage is issued at the top of this iteration iff the load cursor still has work
     const bool issued_now = DYN ? l_valid : (s + NSLOT - 1 < total_stages);
     if (issued_now) issue_stage();
-#ifndef NVIT_PROBE_NO_MFMA
     {
       // Software-pipelined fragment stream.  The stage is 2*FM "steps" of 4 MFMAs (one A fragment against the
       // four B fragments of its k-half).  All ds_read_b128 are written first, in the order the steps consume
@@ -256,15 +237,11 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
     const int r = wr * WROWS + (i_) * 16 + l15;                                                           \
     fa[kk_][i_] = *reinterpret_cast<const uint4*>(la_ + r * ROWB + ((((kk_) * 4 + lg) ^ (r & 7)) << 4));  \
   }
-#ifdef NVIT_PROBE_NO_B_READ   // (probe: B fragments without LDS reads - a third of the fragment traffic)
-#define RB(kk_, j_) { fb[kk_][j_] = make_uint4(0x3c003c00u + (kk_), 0x3c003c00u + (j_), 0x3c003c00u + l15, 0x3c003c00u + lg); }
-#else
 #define RB(kk_, j_)                                                                                       \
   {                                                                                                       \
     const int r = wc * 64 + (j_) * 16 + l15;                                                              \
     fb[kk_][j_] = *reinterpret_cast<const uint4*>(lb_ + r * ROWB + ((((kk_) * 4 + lg) ^ (r & 7)) << 4));  \
   }
-#endif
       __builtin_amdgcn_sched_barrier(0);
       RB(0, 0) RB(0, 1) RB(0, 2) RB(0, 3) RA(0, 0) RA(0, 1) RA(0, 2)
       if constexpr (FM == 8) {
@@ -300,15 +277,11 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
 #undef RA
 #undef RB
     }
-#endif
     bool stored = false, full_tile = false, more = true;
     if (++c_k == nt) {
       int m0, n0;
       tile_of(c_tile, m0, n0);
       full_tile = NST > 0 && m0 + PBM <= g.M && n0 + PBN <= g.N;
-#ifdef NVIT_PROBE_NO_EPI
-      if (g.rowadd_period == -77)   // never true: keeps the accumulators alive without executing the stores
-#endif
       {
         char* scratch = smem + NSLOT * SLOT_BYTES + wid * 2048;
         if constexpr (EPI == 1)

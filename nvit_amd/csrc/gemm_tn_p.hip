@@ -127,14 +127,8 @@ __global__ __launch_bounds__(512) NVIT_TN_VGPR_ATTR void gemm_tn_persistent_kern
       if (l_it < my_items) set_load_item(l_it);
     }
   };
-#ifdef NVIT_PROBE_NO_DMA
-  int probe_issued = 0;
-#endif
   auto issue_stage = [&]() {
     const unsigned bo = lds_base + wave_off + (unsigned)l_slot * TSLOT_BYTES;
-#ifdef NVIT_PROBE_NO_DMA   // tools/probes/gemm_tn_parts.hip: only the first stages are really fetched
-    if (probe_issued++ < NSLOT)
-#endif
 #pragma unroll
     for (int i = 0; i < ODMA; ++i) {
       const bool mok = (l_mbeg + l_t * RB + srow[i]) < l_mend;
@@ -209,7 +203,6 @@ __global__ __launch_bounds__(512) NVIT_TN_VGPR_ATTR void gemm_tn_persistent_kern
     if (s + NSLOT - 1 < total_stages) issue_stage();
     const char* la = smem + slot * TSLOT_BYTES;  // A tile: [m][n]  -> MFMA B operand (cols = n)
     const char* lb = la + OP_BYTES;              // B tile: [m][k'] -> MFMA A operand (rows = k')
-#ifndef NVIT_PROBE_NO_MFMA
     if constexpr (sizeof(T) == 2) {
       // Software-pipelined fragment stream (same idea as gemm_p.hip): 16 steps of 4 MFMAs (one k' fragment of the
       // B tile against the four n fragments of the A tile); every ds_read_b64_tr_b16 pair is written in
@@ -287,7 +280,6 @@ __global__ __launch_bounds__(512) NVIT_TN_VGPR_ATTR void gemm_tn_persistent_kern
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[i], fa[j], acc[i][j], 0, 0, 0);
       }
     }
-#endif
     bool stored = false;
     if (++c_t == c_nt) {
       store_item(c_it);

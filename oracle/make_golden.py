@@ -13,7 +13,17 @@ required at train.py:110-111), so the step driver below re-states its order
 (`ViT.configure_optimizers`) and torch ops; normalize_matrices (train.py:461-480)
 is applied to the reference module's weights with torch ops.
 
-Usage:  python oracle/make_golden.py            (writes tests/golden/*.npz)
+Full-size pins (round 4): the BASELINE configurations themselves - Base (C2) B=6, Large (C4) B=2,
+Base + Kohonen (C5) B=2, post-renorm weight state, the shapes tests/test_gpu_model.py runs - are
+recorded from the imported reference in fp32 (logits, loss, aux losses, per-parameter gradient norms
+and slices, one optimizer step), and the reference's OWN bf16 path (`torch.autocast("cpu",
+dtype=torch.bfloat16)` around `model(X)`, train.py:254,905; logits only) is recorded for
+tiny / mini / base / large / base_k, so that the bf16 deviation of the HIP path is bounded by
+reference-held data: |HIP_bf16 - ref_fp32| <= |ref_autocast_bf16 - ref_fp32|.
+
+Usage:  python oracle/make_golden.py            (writes the small-config tests/golden/*.npz)
+        python oracle/make_golden.py full       (the full-size fp32 pins; minutes of CPU)
+        python oracle/make_golden.py autocast   (the reference's bf16-autocast logits)
 """
 from __future__ import annotations
 
@@ -54,6 +64,8 @@ CASES = [  # (config name, batch)
     ("micro_k", 8),   # Kohonen head (BASELINE config C5 semantics at parity size)
     ("mini_k", 4),
 ]
+FULL_CASES = [("base", 6), ("large", 2), ("base_k", 2)]      # renormed state only (the state the GPU tests run)
+AUTOCAST_CASES = [("tiny", 32), ("mini", 4), ("base", 6), ("large", 2), ("base_k", 2)]
 AUX_KEYS = ("kohonen_consistency", "kohonen_smoothness", "local_quantization", "global_quantization")
 
 
@@ -142,10 +154,53 @@ def one_case(name: str, batch: int, renormed: bool) -> dict:
     return rec
 
 
+def build_ref(name: str, renormed: bool):
+    cfg = named_config(name)
+    ref = RefViT(RefConfig(**asdict(cfg)))
+    res = ref.load_state_dict(formula_state_dict(cfg, perturb_scalars=True), strict=False)
+    assert not res.unexpected_keys and all(k.endswith((".locations", ".offsets")) for k in res.missing_keys), res
+    if renormed:
+        ref_normalize_matrices(ref)
+    return cfg, ref.train()
+
+
+def autocast_case(name: str, batch: int) -> dict:
+    """The reference's own bf16 path on the CPU (train.py:254 builds `torch.autocast(device_type, dtype)`; the
+    forward runs inside it at train.py:905), next to its fp32 path, same weights / inputs, train mode, renormed."""
+    cfg, ref = build_ref(name, True)
+    X, _ = synthetic_batch(cfg, batch)
+    with torch.no_grad():
+        l32, _ = ref(X)
+    cfg, ref = build_ref(name, True)            # fresh module: the Kohonen forward mutates the SOM nodes
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        lbf, _ = ref(X)
+    lbf = lbf.float()
+    d = (lbf - l32).abs()
+    return {"logits_fp32": l32.numpy(), "logits_autocast_bf16": lbf.numpy(),
+            "max_abs_dev": np.float64(d.max().item()), "rms_dev": np.float64(d.double().pow(2).mean().sqrt().item()),
+            "logit_max": np.float64(l32.abs().max().item())}
+
+
 def main() -> None:
-    torch.set_num_threads(4)
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "4")))
     known_answer_check()
     os.makedirs(OUT, exist_ok=True)
+    mode = sys.argv[1] if len(sys.argv) > 1 else "small"
+    if mode == "full":
+        for name, batch in FULL_CASES:
+            rec = one_case(name, batch, True)
+            path = os.path.join(OUT, f"{name}_b{batch}_renorm.npz")
+            np.savez_compressed(path, **rec)
+            print(path, "loss", rec["loss"], "loss1", rec["loss1"], "gnorm", rec["gnorm"], flush=True)
+        return
+    if mode == "autocast":
+        for name, batch in AUTOCAST_CASES:
+            rec = autocast_case(name, batch)
+            path = os.path.join(OUT, f"{name}_b{batch}_autocast.npz")
+            np.savez_compressed(path, **rec)
+            print(path, "ref autocast-bf16 vs ref fp32: max", rec["max_abs_dev"], "rms", rec["rms_dev"],
+                  "|logit|max", rec["logit_max"], flush=True)
+        return
     for name, batch in CASES:
         for renormed in (False, True):
             rec = one_case(name, batch, renormed)

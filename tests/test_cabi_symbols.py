@@ -68,22 +68,19 @@ def test_model_refuses_to_run_without_a_gpu_tensor():
         normalize_matrices(m)
 
 
-def test_product_build_rejects_probe_switches(tmp_path):
-    """The timing-probe switches (NVIT_PROBE_*: cut-down kernels whose results are garbage by design) cannot leak into
-    libnvit_hip.so: the Makefile defines NVIT_PRODUCT_BUILD and common.h turns any probe switch into a build error."""
-    import shutil
-    import subprocess
+def test_product_sources_carry_no_probe_switches():
+    """Timing probes (cut-down kernels whose results are garbage by design) are their own translation units under
+    tools/probes/: no NVIT_PROBE switch exists in the product sources, so no -D can turn libnvit_hip.so into one, and
+    the library is built from exactly the files the Makefile lists."""
+    import glob
+    import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     csrc = os.path.join(root, "nvit_amd", "csrc")
-    assert "-DNVIT_PRODUCT_BUILD" in open(os.path.join(csrc, "Makefile")).read()
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("hipcc not available")
-    src = tmp_path / "probe_guard.hip"
-    src.write_text(f'#include "{csrc}/common.h"\nint main() {{ return 0; }}\n')
-    base = [hipcc, "-std=c++17", "--offload-arch=gfx950", "-fsyntax-only", "-DNVIT_PRODUCT_BUILD", str(src)]
-    ok = subprocess.run(base, capture_output=True, text=True)
-    assert ok.returncode == 0, ok.stderr[-500:]
-    for sw in ("NVIT_PROBE_NO_DMA", "NVIT_PROBE_ATTN_NOEXP", "NVIT_PROBE_V2_NO_DMA"):
-        bad = subprocess.run(base + [f"-D{sw}"], capture_output=True, text=True)
-        assert bad.returncode != 0 and "NVIT_PROBE" in bad.stderr, sw
+    files = glob.glob(os.path.join(csrc, "*.hip")) + glob.glob(os.path.join(csrc, "*.h")) + [os.path.join(root, "include", "nvit_hip.h")]
+    assert len(files) > 10
+    for f in files:
+        hits = [ln for ln in open(f) if re.search(r"#\s*if.*NVIT_PROBE", ln)]
+        assert not hits, (f, hits[:3])
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    listed = set(re.search(r"^SRCS\s*=\s*(.*)$", mk, re.M).group(1).split())
+    assert listed == {os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip"))}
