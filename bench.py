@@ -98,19 +98,6 @@ def pmc_traffic():
         return None, {}, None
 
 
-def _gemm_nt_algorithmic_bytes(cfg, batch: int) -> float:
-    """Average algorithmic HBM bytes of one plain-epilogue gemm_nt launch of the Base-style step: per block o-proj
-    (K=C, fp32 out), mlp_c_proj (K=4C, fp32 out), c_fc dgrad (K=8C, fp32 accumulate: C read + written), qkv dgrad (K=3C,
-    accumulate), att_c_proj dgrad (K=C, bf16 out); A and B are bf16."""
-    C = cfg.n_embd
-    T = (cfg.image_size // cfg.local_patch_size) ** 2
-    M = batch * T
-    def one(K, out_bytes, acc):
-        return 2.0 * M * K + 2.0 * C * K + M * C * out_bytes * (2 if acc else 1)
-    launches = [one(C, 4, False), one(4 * C, 4, False), one(8 * C, 4, True), one(3 * C, 4, True), one(C, 2, False)]
-    return sum(launches) / len(launches)
-
-
 def run_parity(model, cfg, args, X):
     """Parity facts of the benchmarked mode that can be stated without the CPU oracle (which bench.py touches only in
     its cpu_baseline leg): logits of the first 4 images in the benchmarked precision against the exact-f32 mode of the
@@ -172,6 +159,8 @@ def main() -> None:
     ap.add_argument("--precision", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo for rehearsals")
+    ap.add_argument("--collective", default="rccl", choices=["rccl", "xgmi"],
+                    help="gradient exchange: torch.distributed all-reduce (RCCL; default) or the direct xGMI collective")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal only: all ranks use cuda:0 (needs --backend gloo); not a valid benchmark")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
@@ -214,7 +203,8 @@ def main() -> None:
     sync = None
     if world > 1:
         from nvit_amd.parallel import DataParallel
-        dp = DataParallel(model)
+        dp = DataParallel(model, collective=args.collective)
+        dp.profile_exposed(True)
         sync = dp.finish
         step_model = dp
     else:
@@ -264,6 +254,29 @@ def main() -> None:
         dt = t.item()
     if not torch.isfinite(loss).item():
         raise SystemExit("non-finite loss in the timed region")
+    dist_info = None
+    if world > 1:
+        # what the communicator saw, so that a multi-GPU run answers "did RCCL see N ranks on N devices, was the
+        # all-reduce hidden behind backward" by itself
+        prop = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev.index, "name": prop.name,
+                "uuid": str(getattr(prop, "uuid", "")), "pci_bus_id": getattr(prop, "pci_bus_id", None),
+                "exposed_comm_ms_per_step": None}
+        ex = dp.exposed_ms()
+        if ex:
+            ex = ex[-args.steps:]
+            mine["exposed_comm_ms_per_step"] = round(sum(ex) / len(ex), 3)
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        desc = dp.describe()
+        dist_info = {"backend": desc["backend"], "world_size_seen_by_communicator": dist.get_world_size(),
+                     "collective": desc["collective"], "buckets": desc["buckets"], "bucket_bytes": desc["bucket_bytes"],
+                     "grad_bytes_per_step": desc["grad_bytes_per_step"], "gradient_copies_total": desc["copies_total"],
+                     "distinct_devices": len({(e["uuid"], e["pci_bus_id"], e["device_index"]) for e in every}),
+                     "exposed_comm_ms_per_step_max_over_ranks": max((e["exposed_comm_ms_per_step"] or 0.0) for e in every),
+                     "exposed_comm_what": "time the compute stream waits at the end of backward for the last gradient "
+                                          "collective (HIP events around the end-of-backward waits); 0 = fully hidden",
+                     "ranks": every}
 
     # stand-alone nvit_renorm_weights (the kernel north_star singles out; the step itself uses the fused optimizer):
     # 10 warm calls, outside the timed region
@@ -384,11 +397,18 @@ def main() -> None:
         if renorm_warm:
             hbm["renorm_standalone"] = renorm_warm
         out["hbm_kernels"] = hbm
-        if traffic:
-            # plain gemm_nt launches of the step: algorithmic bytes = A + B read once, C written once (per launch average)
-            alg = _gemm_nt_algorithmic_bytes(cfg, args.batch)
-            out["roofline"]["algorithmic_bytes"] = alg
-            out["roofline"]["traffic_over_algorithmic"] = round(traffic / alg, 3)
+        # plain gemm_nt launches of the step: algorithmic bytes = A + B read once, C written once, as each launch declared
+        # them (the same figure the family entry uses, so the two ratios cannot disagree)
+        if g["launches"] and g["bytes"] > 0:
+            alg = g["bytes"] / g["launches"]
+            out["roofline"]["algorithmic_bytes"] = round(alg)
+            if traffic:
+                out["roofline"]["traffic_over_algorithmic"] = round(traffic / alg, 3)
+        out["roofline"]["traffic_measured_in_run"] = False   # PMC counters come from the committed rocprofv3 passes named above
+        out["timed_with_event_profiling"] = not args.graph   # per-launch HIP events are on inside the timed region (eager):
+        # the --graph A/B bounds their cost at 0.3-1.0 ms per Base step, so the headline is if anything conservative
+        if dist_info is not None:
+            out["dist"] = dist_info
         if world == 1:
             out["parity"] = run_parity(model, cfg, args, X)
         if args.check:
@@ -407,6 +427,8 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_sample_batch, threads)
         print(json.dumps(out))
     if world > 1:
+        dp.close()
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -362,11 +362,19 @@ int nvit_xgmi_all_gather(const int64_t* peer_ptrs, int nranks, int rank, int64_t
  *   nvit_xgmi_flags_alloc(nslots, &p, h)    allocate + zero this rank's block, h = 64-byte IPC handle to send to the peers
  *   nvit_xgmi_flags_open(h, &p) / _close(p) map / unmap a peer's block;  nvit_xgmi_flags_free(p) frees the own block
  *   nvit_xgmi_flags_error(own, nslots, &w, stream)   synchronises `stream`, w = 0 or (code << 8 | slot + 1) of the first
- *                                           wait that timed out (20 s): 1 reduce-scatter, 2 all-gather, 3 wait_gathered
+ *                                           wait that timed out ON ANY RANK: 1 reduce-scatter, 2 all-gather, 3 wait_gathered
+ *   nvit_xgmi_set_timeout(seconds)          bound of every device-side wait (default 1800 s = the reference's 30-minute
+ *                                           process-group timeout, train.py:224); set the same value on every rank
+ *   nvit_xgmi_errword_alloc(&host, &dev) / _free(host)   one pinned host word the device can write
+ * A timeout is fatal and fails closed: the timing-out rank stores the error word into EVERY rank's flag block, waits give
+ * up as soon as their own error word is set, a kernel whose wait failed moves no data and announces no phase (nobody
+ * gathers an unreduced chunk), and nvit_xgmi_wait_gathered copies the error word to the pinned host word it is given, so
+ * the host can check it after every step without synchronising.
  * flag_ptrs: HOST array of nranks device pointers to the flag blocks ([rank] = own).  Region = elements [off, off + n) of
  * every symmetric buffer (multiples of 4), chunked by nvit_xgmi_chunk(n, nranks); `epoch` = number of this call for the
  * slot, from 1, the same on every rank.  A region may be rewritten only after nvit_xgmi_wait_gathered has been enqueued
- * for its slot (slots / epochs: DEVICE arrays of nwait entries) on the stream that rewrites it. */
+ * for its slot (slots / epochs: HOST arrays of nwait <= 64 entries, passed to the kernel by value; host_err_dev: the
+ * device pointer from nvit_xgmi_errword_alloc, or NULL) on the stream that rewrites it. */
 int64_t nvit_xgmi_flag_bytes(int nslots);
 int nvit_xgmi_flags_alloc(int nslots, void** dev_ptr, void* ipc_handle_out);
 int nvit_xgmi_flags_open(const void* ipc_handle, void** dev_ptr);
@@ -378,7 +386,10 @@ int nvit_xgmi_reduce_scatter_sync(const int64_t* peer_ptrs, const int64_t* flag_
 int nvit_xgmi_all_gather_sync(const int64_t* peer_ptrs, const int64_t* flag_ptrs, int nranks, int rank, int nslots, int slot,
                               unsigned epoch, int64_t off, int64_t n, void* stream);
 int nvit_xgmi_wait_gathered(const int64_t* flag_ptrs, int nranks, int rank, int nslots, const int* slots,
-                            const unsigned* epochs, int nwait, void* stream);
+                            const unsigned* epochs, int nwait, void* host_err_dev, void* stream);
+int nvit_xgmi_set_timeout(double seconds);
+int nvit_xgmi_errword_alloc(void** host_ptr, void** dev_ptr);
+int nvit_xgmi_errword_free(void* host_ptr);
 
 #ifdef __cplusplus
 }

@@ -94,7 +94,10 @@ SIGNATURES = {
     "nvit_xgmi_flags_error": [_vp, _i, _vp, _vp],
     "nvit_xgmi_reduce_scatter_sync": [_vp, _vp, _i, _i, _i, _i, C.c_uint, _i64, _i64, _f, _vp],
     "nvit_xgmi_all_gather_sync": [_vp, _vp, _i, _i, _i, _i, C.c_uint, _i64, _i64, _vp],
-    "nvit_xgmi_wait_gathered": [_vp, _i, _i, _i, _vp, _vp, _i, _vp],
+    "nvit_xgmi_wait_gathered": [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp],
+    "nvit_xgmi_set_timeout": [C.c_double],
+    "nvit_xgmi_errword_alloc": [_vp, _vp],
+    "nvit_xgmi_errword_free": [_vp],
 }
 _RESTYPES = {"nvit_last_error": C.c_char_p, "nvit_prof_name": C.c_char_p, "nvit_prof_enable": None,
              "nvit_xgmi_chunk": C.c_int64, "nvit_xgmi_flag_bytes": C.c_int64}

@@ -271,22 +271,28 @@ def _lo(rt: _Runtime, x: Tensor, x_lo: Tensor) -> Tensor:
     return x.detach() if rt.dt == F32 else x_lo
 
 
-def _take_carry(rt: "_Runtime", idx: int, chained: bool, dout: Tensor) -> Optional[Tensor]:
-    """The bf16 addend the backward of block idx+1 left for this node (see _Runtime.carry), or None.  It is only valid
-    for the very gradient tensor that node returned: anything else (a hook that replaced the gradient, a second consumer
-    whose gradient autograd summed in) would silently drop or misplace it, so it is checked, not assumed."""
+def _take_carry(rt: "_Runtime", idx: int, chained: bool, dout: Tensor):
+    """(dout, addend): the bf16 addend the backward of block idx+1 left for this node (see _Runtime.carry), or None.  It is
+    only valid for the very gradient tensor that node returned: anything else (a hook that replaced the gradient, a second
+    consumer whose gradient autograd summed in) would silently drop or misplace it, so it is checked, not assumed.
+
+    RESTRICTION of the chained bf16 mode (NVIT_LO_DGRAD=1, the default): the gradient a chained block's backward RETURNS
+    for its input lacks the q/k/v data-gradient part, which travels through `rt.carry` to the next backward node of
+    ViT.forward's chain.  A tensor hook on a block input inside ViT.forward, or `autograd.grad` that stops at one, sees
+    that incomplete gradient; an early stop leaves the addend dangling, which the NEXT forward reports (it raises).
+    Stand-alone `Block.forward` calls are not chained and return complete gradients."""
     c, rt.carry = rt.carry, None
     if c is None:
-        return None
+        return dout, None
     want, dx, add = c
     if not chained or want != idx:
         raise RuntimeError("nvit_amd: pending q/k/v data gradient was not consumed by the block it was produced for")
     if dout.data_ptr() != dx.data_ptr():
         # autograd handed this node a different tensor (gradient hook / extra consumer of the block input): fold the
-        # addend in explicitly and carry on with the plain path
-        dout.add_(add.float())
-        return None
-    return add
+        # addend in explicitly - out of place, the gradient tensor belongs to autograd and may be shared with another
+        # consumer - and carry on with the plain path
+        return dout + add.float(), None
+    return dout, add
 
 
 class _BlockFn(torch.autograd.Function):
@@ -373,7 +379,7 @@ class _BlockFn(torch.autograd.Function):
         dxn = dxn.contiguous()
         lo_dgrad = rt.lo_dgrad and dt != F32
         red = ops.ReduceBatch()   # the block's six parameter-gradient reductions go out as one launch at the end
-        carry_in = _take_carry(rt, idx, ctx.chained, dxn)   # q/k/v data gradient of the block after this one (bf16), or None
+        dxn, carry_in = _take_carry(rt, idx, ctx.chained, dxn)   # q/k/v data gradient of the block after this one (bf16), or None
         # ---- MLP half + norm_skip
         if ctx.with_skip:
             dh1, _, dy2_lo, dx, part_lam, part_skip = ops.lerp_bwd(dt, dxn, h1, y2, mlp_alpha, c_a, x, skip_param,
@@ -520,7 +526,7 @@ class _CrossFn(torch.autograd.Function):
         c_q, c_a = 1.0 / cfg.base_scale, 0.05 / cfg.base_scale
         dx = dx.contiguous()
         red = ops.ReduceBatch()
-        carry_in = _take_carry(rt, -1, ctx.chained, dx)
+        dx, carry_in = _take_carry(rt, -1, ctx.chained, dx)
         dloc, _, dy_lo, _, part_lam, _ = ops.lerp_bwd(dt, dx, loc, y, attn_alpha, c_a, None, None, None,
                                                       False, False, True, dout_add=carry_in)
         d_alpha = _param_grad_alpha(rt, part_lam, p_alpha, c_a, red)
@@ -1033,6 +1039,13 @@ class ViT(nn.Module):
             self.step += 1
         self._prepare(img.device)
         rt = self._rt
+        if rt.carry is not None:
+            # a chained backward stopped before the node that was to consume the pending q/k/v data gradient (autograd.grad
+            # up to a block input, an exception inside backward): the gradients it did return were incomplete
+            rt.carry = None
+            raise RuntimeError("nvit_amd: the previous backward through ViT.forward stopped inside the block chain; in the "
+                               "chained bf16 mode (NVIT_LO_DGRAD=1) gradients at block inputs are incomplete there - set "
+                               "NVIT_LO_DGRAD=0 to differentiate up to an intermediate block input")
         cfg = self.config
         B = img.shape[0]
         T, C = self.n_tokens, cfg.n_embd
@@ -1066,7 +1079,6 @@ class ViT(nn.Module):
                 self._taps["lidx"], self._taps["gidx"] = local_idx.detach(), global_idx.detach()
         else:
             x, x_lo = self.cross_attention._run(loc, glo, loc_lo, glo_lo, chained=True)
-        rt.carry = None
         taps = self._taps
         if taps is not None:
             taps["loc"], taps["glo"], taps["x0"] = loc.detach(), glo.detach(), x.detach()

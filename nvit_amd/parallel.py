@@ -66,7 +66,8 @@ class _Bucket:
 
 class DataParallel(nn.Module):
     def __init__(self, module: nn.Module, process_group=None, bucket_cap_mb: float = 40.0,
-                 broadcast_parameters: bool = True, collective: str = "rccl") -> None:
+                 broadcast_parameters: bool = True, collective: str = "rccl",
+                 xgmi_timeout_s: Optional[float] = None) -> None:
         """collective: "rccl" (default) = bucketed torch.distributed all-reduce overlapped with backward;
         "xgmi" (EXPERIMENTAL: verified with ranks sharing one device only, never timed on links) = the hand-written direct
         reduce-scatter / all-gather over IPC-mapped buffers with device-side phase flags (nvit_amd/xgmi.py):
@@ -78,11 +79,12 @@ class DataParallel(nn.Module):
             raise ValueError("collective must be 'rccl' or 'xgmi' (xgmi: experimental direct collective)")
         self.module = module
         self.collective = collective
+        self.xgmi_timeout_s = xgmi_timeout_s   # None: NVIT_XGMI_TIMEOUT_S or 1800 s (the reference's process-group timeout)
         self._xg = None
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self.bucket_cap = int(bucket_cap_mb * 1024 * 1024)
-        self._avg = dist.get_backend(process_group) == "nccl"
+        self._avg = self._decide_avg(next(module.parameters()).device)
         self._sync = True
         self._buckets: Optional[List[_Bucket]] = None   # built after the first backward
         self._bucket_of = {}
@@ -91,6 +93,7 @@ class DataParallel(nn.Module):
         self._seen = set()
         self._issued = set()
         self.copies = 0   # gradients copied into a bucket by the hook (0 per step once the gradient sink is active)
+        self._exposed = None   # [(event before, event after)] around the end-of-backward waits (profile_exposed)
         if broadcast_parameters:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
@@ -162,15 +165,29 @@ class DataParallel(nn.Module):
             return
         b.handle = self._mean_all_reduce(b.flat, async_op=True)
 
+    def _decide_avg(self, device) -> bool:
+        """Whether the 1/N is folded into the collective (ReduceOp.AVG) - decided ONCE, at construction, and
+        COLLECTIVELY: every rank probes its communicator with a one-element AVG all-reduce and the outcomes are combined
+        with a MIN all-reduce (an op every backend has), so all ranks issue the same collectives for the rest of the run
+        even if one communicator rejects AVG (a per-call `except` fallback would let ranks disagree and hang)."""
+        ok = 0
+        if dist.get_backend(self.group) == "nccl":
+            try:
+                t = torch.full((1,), float(dist.get_rank(self.group) + 1), device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+                ok = int(abs(t.item() - (self.world + 1) / 2.0) < 1e-5)
+            except (RuntimeError, ValueError):
+                ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(flag.item())
+
     def _mean_all_reduce(self, t: torch.Tensor, async_op: bool):
         """Mean over ranks.  On RCCL the 1/N is part of the collective (ReduceOp.AVG: no extra pass over the bucket -
         a separate `div_` was 479 MB of read + write per Base step on the critical stream); gloo (CPU tests and the
-        one-GPU DP tests) has no AVG, there the scale runs before the sum."""
+        one-GPU DP tests) has no AVG, there the scale runs before the sum.  Which of the two was settled in __init__."""
         if self._avg:
-            try:
-                return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
-            except (RuntimeError, ValueError):   # a communicator without AVG: scale, then sum (decided once, on every rank alike)
-                self._avg = False
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
         t.div_(self.world)
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
@@ -231,7 +248,7 @@ class DataParallel(nn.Module):
             if len(buckets) > MAX_SLOTS:
                 raise RuntimeError(f"collective='xgmi': {len(buckets)} buckets, at most {MAX_SLOTS} (raise bucket_cap_mb)")
             self._xg = XgmiAllReduce(sum(b.numel for b in buckets), buckets[0].params[0].device, self.group,
-                                     slots=len(buckets))
+                                     slots=len(buckets), timeout_s=self.xgmi_timeout_s)
             self._comm = torch.cuda.Stream()
         off = 0
         for k, b in enumerate(buckets):
@@ -271,6 +288,10 @@ class DataParallel(nn.Module):
                     if p.grad is None:
                         b.slice_of(i).zero_()
                 self._launch(b)
+        timed = self._exposed is not None and self._first_done and self._buckets and self._buckets[0].flat.is_cuda
+        if timed:   # what the compute stream still has to wait for once backward's own kernels are done = exposed comm
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
         if self._xg is not None:
             # the optimizer (current stream) runs after the last all-gather, and the next backward may rewrite the
             # buckets only when every peer has finished reading them: both are device-side waits, no host round trip
@@ -286,6 +307,32 @@ class DataParallel(nn.Module):
                 b.handle.wait()
                 b.handle = None
             b.pending = len(b.params)
+        if self._xg is not None:
+            self._xg.poll_error()      # one pinned host word, no synchronisation: a timed-out device-side wait raises here
+        if timed:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record(torch.cuda.current_stream())
+            self._exposed.append((e0, e1))
+
+    def profile_exposed(self, on: bool = True) -> None:
+        """Record, per synchronised backward, the time the compute stream spends between the end of backward's own
+        kernels and the completion of the last collective (two events around the end-of-backward waits): the part of the
+        gradient exchange that was NOT hidden behind backward."""
+        self._exposed = [] if on else None
+
+    def exposed_ms(self) -> List[float]:
+        """Per-step exposed communication time in ms (call after a device synchronise)."""
+        return [a.elapsed_time(b) for a, b in (self._exposed or [])]
+
+    def describe(self) -> dict:
+        """What the communicator and the bucket layout look like from this rank (bench.py's `dist` object)."""
+        bk = self._buckets or []
+        return {"backend": dist.get_backend(self.group), "world_size": self.world, "rank": dist.get_rank(self.group),
+                "collective": ("xgmi direct reduce-scatter + all-gather" if self.collective == "xgmi" else
+                               "all_reduce(AVG)" if self._avg else "div_ + all_reduce(SUM)"),
+                "buckets": len(bk), "bucket_bytes": [int(b.numel) * 4 for b in bk],
+                "grad_bytes_per_step": int(sum(b.numel for b in bk)) * 4,
+                "copies_total": self.copies}
 
     def close(self) -> None:
         """Release the direct collective's peer mappings (every rank; no-op for RCCL)."""

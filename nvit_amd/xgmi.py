@@ -17,7 +17,10 @@ are at construction (nobody may start before every rank has opened every handle)
 EXPERIMENTAL on real links.  What is verified: kernels, IPC exchange and the flag protocol with 2-4 ranks SHARING one
 MI355X (`tests/test_gpu_xgmi.py`: skewed ranks, several slots in flight, bit-identical sums); on a multi-GPU node the
 same code reads and signals over the links, which the one-GPU build box cannot execute or time.  Every wait is bounded
-(20 s) and reports through `check_error()` instead of hanging.
+(`timeout_s`, default 1800 s = the reference's process-group timeout, train.py:224).  A timeout is FATAL and fails closed:
+the rank that gives up poisons every rank's error word, no kernel announces a phase after that (nobody gathers an
+unreduced chunk), and `poll_error()` - a read of one pinned host word that the end-of-backward kernel refreshes, no
+synchronisation - raises on every rank within the step (`DataParallel` calls it at the end of every backward).
 
 PyTorch is plumbing here: device memory, the IPC handle exchange for the data buffer (`torch.multiprocessing.reductions`,
 the mechanism behind CUDA tensors in torch.multiprocessing queues) and `torch.distributed` for the handle exchange.
@@ -25,6 +28,7 @@ the mechanism behind CUDA tensors in torch.multiprocessing queues) and `torch.di
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -42,7 +46,8 @@ class XgmiAllReduce:
     `self.buffer` is this rank's symmetric buffer (numel rounded up to a multiple of 4; the padding is zero and is
     reduced like everything else).  `slots`: how many regions may be in flight at once (one flag set each)."""
 
-    def __init__(self, numel: int, device: torch.device, group=None, slots: int = 1) -> None:
+    def __init__(self, numel: int, device: torch.device, group=None, slots: int = 1,
+                 timeout_s: Optional[float] = None) -> None:
         if not dist.is_initialized():
             raise RuntimeError("XgmiAllReduce needs an initialised torch.distributed process group")
         if device.type != "cuda":
@@ -59,6 +64,14 @@ class XgmiAllReduce:
         self.numel = (numel + 3) // 4 * 4
         self.buffer = torch.zeros(self.numel, device=device, dtype=torch.float32)
         lib = _lib.load()
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("NVIT_XGMI_TIMEOUT_S", "1800"))
+        self.timeout_s = float(timeout_s)
+        check(lib.nvit_xgmi_set_timeout(self.timeout_s), "nvit_xgmi_set_timeout")
+        hp, dp = C.c_void_p(), C.c_void_p()
+        check(lib.nvit_xgmi_errword_alloc(C.byref(hp), C.byref(dp)), "nvit_xgmi_errword_alloc")
+        self._err_host, self._err_dev = hp.value, dp.value
+        self._err_view = C.cast(self._err_host, C.POINTER(C.c_uint))
         # ---- which device is every rank on?  Ranks on different devices need peer access (xGMI / PCIe P2P).
         idx = device.index if device.index is not None else torch.cuda.current_device()
         props = torch.cuda.get_device_properties(idx)
@@ -143,31 +156,44 @@ class XgmiAllReduce:
         slots = [s for s in slots if self._epoch[s] > 0]
         if not slots:
             return
-        dev_slots = torch.tensor(slots, dtype=torch.int32, device=self.device)
-        dev_epochs = torch.tensor([self._epoch[s] for s in slots], dtype=torch.int64, device=self.device).to(torch.int32)
-        check(_lib.load().nvit_xgmi_wait_gathered(self._fptrs, self.world, self.rank, self.slots, dev_slots.data_ptr(),
-                                                  dev_epochs.data_ptr(), len(slots), _s() if stream is None else stream),
+        # slots and epochs travel BY VALUE in the kernel arguments: no device array, no pageable host-to-device copy (which
+        # torch follows with a stream synchronise), nothing to keep alive, capturable in a hipGraph
+        h_slots = (C.c_int * len(slots))(*slots)
+        h_epochs = (C.c_uint * len(slots))(*[self._epoch[s] & 0xFFFFFFFF for s in slots])
+        check(_lib.load().nvit_xgmi_wait_gathered(self._fptrs, self.world, self.rank, self.slots, h_slots, h_epochs,
+                                                  len(slots), self._err_dev, _s() if stream is None else stream),
               "nvit_xgmi_wait_gathered")
-        self._keep = (dev_slots, dev_epochs)   # alive until the next call (the kernel reads them)
 
     def all_reduce_(self, scale: float = 1.0, numel: Optional[int] = None, slot: int = 0, off: int = 0) -> torch.Tensor:
         """buffer[off : off + numel] <- scale * sum over ranks (bit-identical on every rank), stream-ordered on the current
-        stream: safe to read and to rewrite the region in later work of that stream.  No host synchronisation."""
+        stream: safe to read and to rewrite the region in later work of that stream.  Three kernel launches, no host
+        synchronisation and no host-to-device copy."""
         e = self.begin(slot)
         self.reduce_scatter_(slot, e, scale, off, numel)
         self.all_gather_(slot, e, off, numel)
         self.wait_gathered([slot])
         return self.buffer
 
+    def _raise(self, w: int) -> None:
+        what = {1: "reduce-scatter waiting for the peers' gradients", 2: "all-gather waiting for the peers' reduced chunks",
+                3: "waiting for the peers to finish reading"}.get(w >> 8, "?")
+        raise RuntimeError(f"XgmiAllReduce (rank {self.rank}): a device-side wait timed out after {self.timeout_s:g} s on some "
+                           f"rank ({what}, slot {(w & 0xff) - 1}); the collective failed closed - gradients of this and "
+                           "later steps were NOT reduced, the replicas must not continue")
+
+    def poll_error(self) -> None:
+        """Non-blocking: raise if the pinned host copy of the error word (refreshed by every wait_gathered kernel) is set.
+        Lags the device by at most the kernels still in flight, i.e. a failure surfaces within a step."""
+        w = int(self._err_view[0])
+        if w:
+            self._raise(w)
+
     def check_error(self) -> None:
-        """Synchronise the current stream and raise if any device-side wait timed out (a dead or diverged peer)."""
+        """Synchronise the current stream and raise if any device-side wait timed out on any rank."""
         w = C.c_uint(0)
         check(_lib.load().nvit_xgmi_flags_error(self._own_flags, self.slots, C.byref(w), _s()), "nvit_xgmi_flags_error")
         if w.value:
-            what = {1: "reduce-scatter waiting for the peers' gradients", 2: "all-gather waiting for the peers' reduced chunks",
-                    3: "waiting for the peers to finish reading"}.get(w.value >> 8, "?")
-            raise RuntimeError(f"XgmiAllReduce: device-side wait timed out on rank {self.rank} ({what}, slot "
-                               f"{(w.value & 0xff) - 1})")
+            self._raise(w.value)
 
     def close(self) -> None:
         """Drop the peer mappings (every rank, before the owners free their buffers)."""
@@ -183,3 +209,5 @@ class XgmiAllReduce:
         self._host_barrier()     # nobody still maps this rank's flag block
         check(lib.nvit_xgmi_flags_free(self._own_flags), "nvit_xgmi_flags_free")
         self._own_flags = None
+        check(lib.nvit_xgmi_errword_free(self._err_host), "nvit_xgmi_errword_free")
+        self._err_host = self._err_dev = self._err_view = None

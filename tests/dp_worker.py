@@ -18,10 +18,14 @@ from nvit_amd.train import total_loss
 from nvit_amd.weights import formula_state_dict, synthetic_batch
 
 
+PRECISION = os.environ.get("NVIT_DP_TEST_PRECISION", "fp32")
+BUCKET_CAP_MB = float(os.environ.get("NVIT_DP_TEST_CAP_MB", "0.25"))
+
+
 def make(cfg):
     m = ViT(cfg)
     m.load_state_dict(formula_state_dict(cfg), strict=False)
-    return m.to("cuda:0").set_precision("fp32").train()
+    return m.to("cuda:0").set_precision(PRECISION).train()
 
 
 def grads_of(m):
@@ -48,7 +52,7 @@ def main():
         with torch.no_grad():
             for p in m.parameters():
                 p.add_(0.5)
-    dp = DataParallel(m, bucket_cap_mb=0.25, collective=collective)
+    dp = DataParallel(m, bucket_cap_mb=BUCKET_CAP_MB, collective=collective)
     opt = m.configure_optimizers(0.1, 1e-3, (0.9, 0.95), "cuda")
     res = {"rank": rank, "config": name}
 
@@ -91,6 +95,7 @@ def main():
             ropt.zero_grad(set_to_none=True)
     res["grad_err_vs_single_process"] = worst_by_step
     res["buckets"] = dp.num_buckets
+    res["describe"] = dp.describe()
     if koh:
         nodes = torch.cat([m.local_kohonen.nodes.detach().flatten(), m.global_kohonen.nodes.detach().flatten()]).cpu()
         both = [torch.empty_like(nodes) for _ in range(world)]

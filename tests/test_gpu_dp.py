@@ -26,12 +26,12 @@ def _free_port():
     return p
 
 
-def _run(name, tmp_path, collective="rccl", world=2):
+def _run(name, tmp_path, collective="rccl", world=2, **extra_env):
     port = _free_port()
     procs, outs = [], []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
         out = tmp_path / f"{name}_{rank}.json"
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), name, str(out), collective],
@@ -39,7 +39,7 @@ def _run(name, tmp_path, collective="rccl", world=2):
     logs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=300)
+            o, _ = p.communicate(timeout=600)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
@@ -109,3 +109,36 @@ def test_dp_four_ranks_real_model(tmp_path, collective):
     assert r0["grad_err_vs_single_process"][0] < 5e-6, r0
     assert max(r0["grad_err_vs_single_process"]) < 3e-4 and r0["param_err_vs_single_process"] < 1e-4, r0
     assert r0["accum_err_vs_single_process"] < 3e-4, r0
+
+
+@pytest.mark.parametrize("collective", ["rccl", "xgmi"])
+def test_dp_base_size_bucket_layout_and_gradients(tmp_path, collective):
+    """The BASELINE model (nViT-Base, C2) under data parallelism with the DEFAULT bucket size, in the benchmarked bf16
+    mode: two fresh processes share the GPU over gloo, 4 images per rank, against the single-process run on the 8 images.
+    Asserts what the 8-GPU run relies on: the bucket layout (13 buckets: every nGPT block of 37.8 MB in a bucket of its
+    own - the last block shares with the head, the first with one cross-attention matrix - plus one of 19.6 MB for the
+    rest of the cross-attention block and the embeddings; 479 MB per step), gradients produced inside the buckets (at most 12 small vector gradients copied per step, the stacked q/k/v
+    gradient written straight into its slices), every slice 16-byte aligned, all-reduced gradients bit-identical on both
+    ranks and equal to the single-process gradient, for the torch.distributed collective and for the direct one."""
+    res = _run("base", tmp_path, collective=collective, NVIT_DP_TEST_PRECISION="bf16", NVIT_DP_TEST_CAP_MB="40")
+    C, L = 768, 12
+    block_params = 16 * C * C + 11 * C + 1          # six matrices + attn_alpha, mlp_alpha, sqk, suv (8C), skip_param
+    for r in res:
+        d = r["describe"]
+        print(json.dumps(d))
+        assert d["world_size"] == 2 and d["backend"] == "gloo"
+        assert d["buckets"] == r["buckets"] == 13, d
+        assert sum(1 for b in d["bucket_bytes"] if b >= 4 * block_params) == L, d["bucket_bytes"]
+        assert sum(1 for b in d["bucket_bytes"] if 4 * block_params <= b <= 4 * (block_params + 64)) == L - 2, d["bucket_bytes"]
+        assert max(d["bucket_bytes"]) <= 40 * 1024 * 1024
+        assert all(b % 16 == 0 for b in d["bucket_bytes"])
+        # 119.77 M parameters, minus the ones that never get a gradient (rmsnorm_*, reconstruction head: SURVEY 9.1-Q6)
+        assert 470e6 < d["grad_bytes_per_step"] < 480e6, d
+        for step in range(3):
+            assert r[f"ranks_equal_step{step}"] and r[f"aligned_step{step}"]
+        assert r["copies_step1"] == r["copies_step2"] <= 12 < r["n_grads"], r
+        assert r["params_equal_across_ranks"]
+    r0 = res[0]
+    print("gradient error vs single process per step:", r0["grad_err_vs_single_process"])
+    assert r0["grad_err_vs_single_process"][0] < 2e-5, r0      # same weights: fp32 summation order of the batch halves only
+    assert r0["accum_err_vs_single_process"] < 5e-3, r0

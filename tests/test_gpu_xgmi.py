@@ -25,8 +25,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_xgmi_all_reduce_shared_device(world, tmp_path):
+def _spawn(world, tmp_path, *extra):
     port = _free_port()
     procs, outs = [], []
     for rank in range(world):
@@ -34,7 +33,7 @@ def test_xgmi_all_reduce_shared_device(world, tmp_path):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         out = tmp_path / f"x_{rank}.json"
         outs.append(out)
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "xgmi_worker.py"), str(out)], env=env,
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "xgmi_worker.py"), str(out), *extra], env=env,
                                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
     for p in procs:
@@ -47,8 +46,25 @@ def test_xgmi_all_reduce_shared_device(world, tmp_path):
         logs.append(o)
     if any(p.returncode != 0 for p in procs):
         raise AssertionError("\n".join(f"--- rank {i} rc={p.returncode}\n{o[-1500:]}" for i, (p, o) in enumerate(zip(procs, logs))))
-    for out in outs:
-        r = json.load(open(out))
+    return [json.load(open(out)) for out in outs]
+
+
+def test_xgmi_timeout_is_fatal_on_every_rank_and_fails_closed(tmp_path):
+    """A rank that arrives later than the bound (1 s here; 1800 s by default): the waiting rank gives up and poisons every
+    rank's error word, the late rank's kernels find it, both raise from the pinned host word within the call, no buffer
+    holds a partially reduced / gathered result, a second call returns at once and raises again, nothing hangs."""
+    res = _spawn(2, tmp_path, "late")
+    for r in res:
+        assert r["raised"] and "timed out" in r["message"], r
+        assert r["buffer_untouched"], r
+        assert r["second_raised"] and r["second_seconds"] < 1.0, r
+        assert r["check_error_raised"], r
+        assert r["seconds"] < 10.0, r
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_xgmi_all_reduce_shared_device(world, tmp_path):
+    for r in _spawn(world, tmp_path):
         assert len(r["cases"]) == 4 and r["shared_device"]
         assert r["multi_slot"]["max_err"] < 1e-5 and r["multi_slot"]["bit_identical_across_ranks"], r["multi_slot"]
         for c in r["cases"]:

@@ -19,12 +19,56 @@ def fill(rank, n, step, dev):
     return torch.sin(i * (0.001 * (rank + 1))) * (1.0 + rank) + step * 0.125
 
 
+def late_rank(out_path, rank, world, dev):
+    """A rank that arrives later than the timeout (the last rank sleeps 3x the 1 s bound before its collective): the
+    waiting ranks must give up, EVERY rank must see the failure (also the late one, whose kernels find the poisoned
+    error word), no rank may end up with a partially reduced or gathered buffer, and nothing may hang."""
+    n = 1 << 20
+    ar = XgmiAllReduce(n, dev, slots=2, timeout_s=1.0)
+    ar.buffer[:] = fill(rank, n, 0, dev)
+    before = ar.buffer.clone()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.time()
+    if rank == world - 1:
+        time.sleep(3.0)
+    res = {"rank": rank, "raised": False}
+    try:
+        ar.all_reduce_(1.0 / world, numel=n)
+        torch.cuda.synchronize()
+        ar.poll_error()           # the pinned host word, as DataParallel reads it at the end of backward
+    except RuntimeError as e:
+        res["raised"], res["message"] = True, str(e)
+    res["seconds"] = time.time() - t0
+    res["buffer_untouched"] = bool(torch.equal(ar.buffer, before))
+    try:                          # a second call on the poisoned communicator returns at once and raises again
+        t1 = time.time()
+        ar.all_reduce_(1.0 / world, numel=n, slot=1)
+        torch.cuda.synchronize()
+        ar.poll_error()
+        res["second_raised"] = False
+    except RuntimeError:
+        res["second_raised"] = True
+    res["second_seconds"] = time.time() - t1
+    try:
+        ar.check_error()
+        res["check_error_raised"] = False
+    except RuntimeError:
+        res["check_error_raised"] = True
+    ar.close()
+    json.dump(res, open(out_path, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     out_path = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", init_method="env://")
+    if len(sys.argv) > 2 and sys.argv[2] == "late":
+        return late_rank(out_path, rank, world, dev)
     res = {"rank": rank, "world": world, "cases": []}
     sizes = (4, 1000, 1 << 20, 9437185)     # incl. sizes that are not multiples of 4 * world, and one nGPT block + 1
     ar = XgmiAllReduce(max(sizes), dev, slots=4)   # ONE symmetric buffer (one IPC export per process); prefixes of it are reduced
