@@ -78,8 +78,12 @@ def main():
         res["n_grads"] = len(g)
         if ref is not None:
             backward(ref, X.cuda(), y.cuda())
-            for n, t in grads_of(ref).items():
-                worst = max(worst, rel(g[n], t))
+            per = {n: rel(g[n], t) for n, t in grads_of(ref).items()}
+            big = {n: e for n, e in per.items() if g[n].numel() > 16}      # scalars (skip_param) are reported apart: in
+            worst = max(big.values())                                      # bf16 mode they are cancellation-dominated
+            if step == 0:
+                res["worst_params_step0"] = sorted(((e, n) for n, e in per.items()), reverse=True)[:6]
+                res["scalar_err_step0"] = max([e for n, e in per.items() if g[n].numel() <= 16] or [0.0])
         worst_by_step.append(worst)
         # cross-rank equality of the reduced gradients
         flat = torch.cat([t.flatten() for t in g.values()]).cpu()
