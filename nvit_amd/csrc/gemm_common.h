@@ -309,6 +309,10 @@ __device__ __forceinline__ void nt_store_tile_qknorm(const NtArgs& g, f32x4 (&ac
   for (int j = 0; j < 4; ++j) sc[j] = *reinterpret_cast<const f32x4*>(g.sqk + c0 + j * 16 + 4 * lg) * cq;
   bf16* outp = reinterpret_cast<bf16*>(part == 0 ? g.qh : (part == 1 ? g.kh : g.vh));
   float* rn_out = part == 0 ? g.rq : g.rk;
+  // (batch, token) of the wave tile's first row: ONE integer division per call - a division by the run-time token count
+  // per stored row (16 per lane per tile, ~30 VALU instructions each) was as much VALU work as the rest of this epilogue
+  // (round 4: -2 % on the q/k/v GEMM, interleaved A/B)
+  const int b_base = m_base / g.Ttok, t_base = m_base - b_base * g.Ttok;
 #pragma unroll
   for (int i = 0; i < FMR; ++i) {
     float rn = 1.0f;
@@ -339,7 +343,11 @@ __device__ __forceinline__ void nt_store_tile_qknorm(const NtArgs& g, f32x4 (&ac
       const uint4 raw = *reinterpret_cast<const uint4*>(scratch + row * 128 + ((chunk ^ (row & 7)) << 4));
       const int m = m_base + i * 16 + row;
       if (m < g.M) {
-        const int b = m / g.Ttok, tt = m - b * g.Ttok;
+        int b = b_base, tt = t_base + i * 16 + row;
+        while (tt >= g.Ttok) {   // at most once when Ttok >= the tile's 128 rows
+          tt -= g.Ttok;
+          ++b;
+        }
         st16_nt(outp + (((size_t)b * g.H + h) * g.Ttok + tt) * 64 + chunk * 8, raw);
       }
     }

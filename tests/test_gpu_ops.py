@@ -223,6 +223,47 @@ def test_lerp_fwd_bwd(C, with_skip):
         assert abs(ds.item() - skip.grad.item()) < 1e-4 * max(1.0, abs(skip.grad.item()))
 
 
+@pytest.mark.parametrize("C", [128, 768, 1024, 1280])
+@pytest.mark.parametrize("with_skip", [False, True])
+def test_lerp_bwd_bf16_addend_and_accumulate(C, with_skip):
+    """The backward row kernel as the bf16 step calls it: y stored in bf16, the incoming gradient = an fp32 tensor + a
+    bf16 addend (the data-gradient GEMM's output), dh accumulated onto an existing tensor, dy written in bf16 only; W =
+    ceil(C / 256) waves share a row (1, 3, 4 and 5 here), ragged row count, against fp64 autograd on the same values."""
+    ops = ops_()
+    from nvit_amd._lib import BF16
+    M = 517
+    d = dev()
+    h32 = rnd(M, C, seed=11)
+    yb = rnd(M, C, seed=12, scale=0.3).bfloat16()
+    alpha32 = rnd(C, seed=13, scale=0.01) + 1 / 32
+    xs32, g32 = rnd(M, C, seed=14), rnd(M, C, seed=15)
+    addb = rnd(M, C, seed=16, scale=0.5).bfloat16()
+    old = rnd(M, C, seed=17)
+    skip32 = torch.tensor([0.9])
+    c_a = 0.05 * 32
+    h, y, alpha, xs, skip = (t.double().requires_grad_(True) for t in (h32, yb.float(), alpha32, xs32, skip32))
+    out = O.lerp(h, y, alpha, c_a)
+    if with_skip:
+        out = O.nrm(out * skip + xs)
+    out.backward(g32.double() + addb.double())
+    dh0 = old.clone().to(d)
+    dh, dy, dy_lo, dxs, part, pskip = ops.lerp_bwd(BF16, g32.to(d), h32.to(d), yb.to(d), alpha32.to(d), c_a,
+                                                   xs32.to(d) if with_skip else None, skip32.to(d) if with_skip else None,
+                                                   dh0, True, False, True, dout_add=addb.to(d))
+    assert dh.data_ptr() == dh0.data_ptr() and dy is None
+    want_dh = (old.double() + h.grad)
+    assert (dh.cpu().double() - want_dh).abs().max().item() < 3e-6 * max(1.0, want_dh.abs().max().item())
+    assert (dy_lo.float().cpu().double() - y.grad).abs().max().item() < 5e-3 * y.grad.abs().max().item()   # one bf16 rounding
+    da = torch.empty(C, device=d)
+    ops.colsum_reduce(part, da, False, kind=1, ref=alpha32.to(d), scale=c_a)
+    assert (da.cpu().double() - alpha.grad).abs().max().item() < 1e-4 * max(1.0, alpha.grad.abs().max().item())
+    if with_skip:
+        assert (dxs.cpu().double() - xs.grad).abs().max().item() < 3e-6 * max(1.0, xs.grad.abs().max().item())
+        ds = torch.empty(1, device=d)
+        ops.colsum_reduce(pskip, ds, False)
+        assert abs(ds.item() - skip.grad.item()) < 1e-4 * max(1.0, abs(skip.grad.item()))
+
+
 @pytest.mark.parametrize("H,d", [(2, 32), (3, 64), (12, 64)])
 def test_qknorm_fwd_bwd(H, d):
     ops = ops_()

@@ -34,9 +34,16 @@ def rows_fwd():
         ops.lerp_fwd(BF16, h, y, alpha, 1.6, want_lo=True)
 
 
-def rows_bwd():
-    for _ in range(NROW // 2):
-        ops.lerp_bwd(BF16, dout, h, y, alpha, 1.6, None, None, None, False, False, True)
+yb = y.bfloat16()
+add = torch.randn(M, C, device=dev).bfloat16()
+xs = torch.nn.functional.normalize(torch.randn(M, C, device=dev), dim=-1)
+skip = torch.tensor([0.9], device=dev)
+dh_acc = torch.zeros(M, C, device=dev)
+
+
+def rows_bwd():   # the two backward row kernels of a block as the step calls them
+    ops.lerp_bwd(BF16, dout, h, yb, alpha, 1.6, xs, skip, None, False, False, True, dout_add=add)
+    ops.lerp_bwd(BF16, dout, h, yb, alpha, 1.6, None, None, dh_acc, True, False, True, dout_add=add)
 
 
 def timed(fn, reps=5):
@@ -62,7 +69,7 @@ def both_streams(rows):
     return f
 
 
-for rows, tag in ((rows_fwd, f"{NROW} x lerp_fwd (72 VGPRs)"), (rows_bwd, f"{NROW // 2} x lerp_bwd (160 VGPRs, 12 KiB LDS)")):
+for rows, tag in ((rows_fwd, f"{NROW} x lerp_fwd (72 VGPRs)"), (rows_bwd, "lerp_bwd MLP half + attention half")):
     for mode, mtag in ((5, "TN 2x64KiB ring, 230 VGPRs"), (3, "TN 4x32KiB ring, 193 VGPRs")):
         lib.nvit_set_tn_order(mode)
         res = {k: [] for k in ("gemm", "rows", "serial", "two_streams")}
