@@ -115,15 +115,18 @@ def run_parity(model, cfg, args, X):
     out = {"what": f"{args.precision} logits vs the exact-f32 mode of the same model, first 4 images of the batch",
            "max_abs": float(f"{d.max().item():.3e}"), "rms": float(f"{d.double().pow(2).mean().sqrt().item():.3e}"),
            "logit_max_abs": round(lmax, 3), "max_rel_to_logit_range": float(f"{d.max().item() / lmax:.3e}"),
-           "fp32_mode_vs_cpu_oracle": "<= 1e-5 (tests/test_gpu_model.py, Base B=6: 2.1e-6)"}
+           "fp32_mode_vs_reference": "<= 1e-5 against golden vectors of the imported reference at this model size "
+                                     "(tests/test_gpu_model.py, Base B=6: 1.7e-6; one full step later 5.2e-6)"}
     if args.precision == "bf16":
         out["north_star_tolerance"] = 1e-3
         out["meets_1e-3_vs_fp32"] = bool(d.max().item() < 1e-3)
         out["documented_deviation"] = (
             "beyond the small configs the bf16 rounding of the GEMM operands alone moves the ORACLE's logits by more than "
-            "1e-3 (Base 2.7e-3, Large 4.0e-3; the reference's own autocast path 7.2e-3 at Base, SURVEY 9.3); the tests hold "
-            "the HIP path to 1e-3 of the CPU oracle that rounds the same operands at the same points, and two such "
-            "evaluations that differ only in summation order already differ by 4.5e-4 (Base) / 7.1e-4 (Large): DESIGN.md 2")
+            "1e-3 (Base 2.7e-3, Large 4.0e-3; activations alone 1.13e-3 at Large); the primary bar is reference-held: "
+            "|HIP_bf16 - ref_fp32| <= |ref_autocast_bf16 - ref_fp32| on fixtures recorded from the imported reference "
+            "(tests/golden/*_autocast.npz: Base B=6 2.87e-3 vs 7.7e-3, Large B=2 4.27e-3 vs 8.9e-3, Base+Kohonen B=2 "
+            "2.39e-3 vs 1.5e-2; profiles/r04_parity_margins.json); secondary: within 1e-3 of the CPU evaluation that rounds "
+            "the same operands at the same points (DESIGN.md 2)")
     return out
 
 
@@ -270,7 +273,8 @@ def main() -> None:
         dist.all_gather_object(every, mine)
         desc = dp.describe()
         dist_info = {"backend": desc["backend"], "world_size_seen_by_communicator": dist.get_world_size(),
-                     "collective": desc["collective"], "buckets": desc["buckets"], "bucket_bytes": desc["bucket_bytes"],
+                     "collective": desc["collective"], "gemm_tile_schedule": desc["gemm_tile_schedule"],
+                     "buckets": desc["buckets"], "bucket_bytes": desc["bucket_bytes"],
                      "grad_bytes_per_step": desc["grad_bytes_per_step"], "gradient_copies_total": desc["copies_total"],
                      "distinct_devices": len({(e["uuid"], e["pci_bus_id"], e["device_index"]) for e in every}),
                      "exposed_comm_ms_per_step_max_over_ranks": max((e["exposed_comm_ms_per_step"] or 0.0) for e in every),
@@ -307,6 +311,8 @@ def main() -> None:
               f"peak {peak:.1f} TFLOP/s (nominal {NOMINAL_PEAK_BF16_TFLOPS})", file=sys.stderr, flush=True)
 
         traffic, fam_traffic, traffic_src = pmc_traffic()
+        if not (args.config == "base" and args.batch == 128 and args.precision == "bf16"):
+            traffic, fam_traffic, traffic_src = None, {}, None   # the committed PMC passes are of the default workload only
 
         def fam_of(key, label, executed_mult=1.0, pmc_key=None):
             """MFMA view (algorithmic FLOPs / HIP-event time vs the dense bf16 peak) and HBM view (algorithmic bytes

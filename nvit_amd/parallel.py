@@ -28,6 +28,7 @@ Works with any backend of torch.distributed ("nccl" = RCCL on ROCm; "gloo" for t
 """
 from __future__ import annotations
 
+import os
 from contextlib import contextmanager
 from typing import List, Optional
 
@@ -108,6 +109,15 @@ class DataParallel(nn.Module):
         self._params = [p for p in module.parameters() if p.requires_grad]
         for p in self._params:
             p.register_post_accumulate_grad_hook(self._hook)
+        # The persistent GEMMs take one workgroup per CU; a collective's kernels (RCCL's, or the direct xGMI ones) that run
+        # under backward hold some CUs for a while, and a statically dealt GEMM then waits for its slowest workgroup (+13 %
+        # per GEMM with 32-64 CUs pinned; tools/sched_interference.py).  With dynamic tile hand-out the late
+        # workgroups simply take fewer tiles (+2-4 %) at a cost of 0.8 % of an undisturbed step: the default under data
+        # parallelism (NVIT_GEMM_SCHED=s keeps the static deal; the single-process default stays static).
+        self.gemm_sched = os.environ.get("NVIT_GEMM_SCHED", "d" if self.world > 1 else "s")
+        if next(module.parameters()).is_cuda:
+            from . import _lib
+            _lib.load().nvit_set_gemm_sched(1 if self.gemm_sched[:1] in ("d", "1") else 0)
 
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
@@ -330,6 +340,7 @@ class DataParallel(nn.Module):
         return {"backend": dist.get_backend(self.group), "world_size": self.world, "rank": dist.get_rank(self.group),
                 "collective": ("xgmi direct reduce-scatter + all-gather" if self.collective == "xgmi" else
                                "all_reduce(AVG)" if self._avg else "div_ + all_reduce(SUM)"),
+                "gemm_tile_schedule": "dynamic" if self.gemm_sched[:1] in ("d", "1") else "static",
                 "buckets": len(bk), "bucket_bytes": [int(b.numel) * 4 for b in bk],
                 "grad_bytes_per_step": int(sum(b.numel for b in bk)) * 4,
                 "copies_total": self.copies}
