@@ -391,6 +391,12 @@ int nvit_xgmi_set_timeout(double seconds);
 int nvit_xgmi_errword_alloc(void** host_ptr, void** dev_ptr);
 int nvit_xgmi_errword_free(void* host_ptr);
 
+/* Attention backward, dK/dV kernel: 1 = the hand-placed (generated-assembly) main loop where it applies (pre-scaled q,
+ * the fused entry point; default, NVIT_ATTN_DKV_ASM=0 turns it off), 0 = the compiler-built kernel.  Both compute
+ * bit-identical results (tests/test_gpu_ops.py). */
+int nvit_set_attn_dkv_asm(int on);
+int nvit_attn_dkv_asm_occupancy(void);   /* diagnostic: resident workgroups per CU of that kernel (occupancy query) */
+
 #ifdef __cplusplus
 }
 #endif
