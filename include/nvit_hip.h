@@ -395,7 +395,6 @@ int nvit_xgmi_errword_free(void* host_ptr);
  * the fused entry point; default, NVIT_ATTN_DKV_ASM=0 turns it off), 0 = the compiler-built kernel.  Both compute
  * bit-identical results (tests/test_gpu_ops.py). */
 int nvit_set_attn_dkv_asm(int on);
-int nvit_attn_dkv_asm_occupancy(void);   /* diagnostic: resident workgroups per CU of that kernel (occupancy query) */
 
 #ifdef __cplusplus
 }

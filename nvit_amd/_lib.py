@@ -99,7 +99,6 @@ SIGNATURES = {
     "nvit_xgmi_errword_alloc": [_vp, _vp],
     "nvit_xgmi_errword_free": [_vp],
     "nvit_set_attn_dkv_asm": [_i],
-    "nvit_attn_dkv_asm_occupancy": [],
 }
 _RESTYPES = {"nvit_last_error": C.c_char_p, "nvit_prof_name": C.c_char_p, "nvit_prof_enable": None,
              "nvit_xgmi_chunk": C.c_int64, "nvit_xgmi_flag_bytes": C.c_int64}

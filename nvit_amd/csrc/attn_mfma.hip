@@ -964,211 +964,20 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
 // ------------------------------------------------------------------------------------------ dK, dV: hand-placed main loop
 // Same arithmetic, operand layouts and accumulation order as attn_bwd_dkv_mfma_kernel above (bit-exact against it), for
 // the pre-scaled-q case (c2 = 1), with the tile loop written as ONE generated inline-asm statement
-// (gen/gen_attn_dkv_asm.py -> attn_dkv_asm.inc; structure and numbers: DESIGN.md section 5, round 4): a workgroup = 2 waves
-// x 64 keys, one wave per SIMD with the whole 512-entry register file (dK/dV accumulators, K/V fragments and the
-// transposed Q/dO fragments in the accumulation half), a three-stage software pipeline over (32-query half, key fragment)
-// groups in which every dependency crosses a step boundary, fragment reads one half ahead, Q/dO tiles two tiles ahead by
-// LDS-DMA.  The compiler-built code around it only prepares operands and stores the result: the accumulators come back
-// through LDS (ds_write from the accumulation registers), never through compiler-visible registers.
-#include "attn_dkv_asm.inc"
-
+// (gen/gen_attn_dkv32_asm.py -> attn_dkv32_asm.inc; structure and numbers: DESIGN.md section 5, round 4).  The
+// compiler-built code around it only prepares operands and stores the result: the accumulators come back through LDS
+// (ds_write from the accumulation registers), never through compiler-visible registers.
 __device__ __forceinline__ unsigned uni32(unsigned x) { return (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
 __device__ __forceinline__ unsigned long long uni64(const void* p) {
   const unsigned long long u = (unsigned long long)(uintptr_t)p;
   return (unsigned long long)uni32((unsigned)u) | ((unsigned long long)uni32((unsigned)(u >> 32)) << 32);
 }
 
-// The q/k-normalise backward of qk_bwd_epilogue for the two 32-key halves of a wave's 64 keys (virtual waves 2*wid, 2*wid+1
-// of the 128-key block: same arithmetic and summation order, so the results are bit-identical), with every global load of
-// both halves issued before the first use (the epilogue of a one-wave-per-SIMD kernel has no partner wave to hide them).
-struct QkRowsIn {
-  uint2 xr[2][2][4];   // [half][f][df] saved unit-direction rows
-  float rn[2][2];
-  f32x4 s[4];
-};
-__device__ __forceinline__ void qk_rows_load(QkRowsIn& in, const bf16* xh_bh, const QkFuse& fu, int k0, int T, int H, int b,
-                                             int h, int lane) {
-  const int l15 = lane & 15, lg = lane >> 4;
-#pragma unroll
-  for (int hk = 0; hk < 2; ++hk)
-#pragma unroll
-    for (int f = 0; f < 2; ++f) {
-      const int row = k0 + 32 * hk + 16 * f + l15;
-      const int rc = row < T ? row : T - 1;
-#pragma unroll
-      for (int df = 0; df < 4; ++df)
-        in.xr[hk][f][df] = *reinterpret_cast<const uint2*>(xh_bh + (size_t)rc * 64 + df * 16 + 4 * lg);
-      in.rn[hk][f] = fu.rn[((size_t)b * T + rc) * H + h];
-    }
-#pragma unroll
-  for (int df = 0; df < 4; ++df) in.s[df] = *reinterpret_cast<const f32x4*>(fu.sqk + h * 64 + df * 16 + 4 * lg) * fu.c_q;
-}
-__device__ __forceinline__ void qk_bwd_rows(f32x4 (&g)[4][2], const QkRowsIn& in, int hk, const QkFuse& fu, int row0, int T,
-                                            int b, int h, int lane, char* scr, float* red_vw) {
-  const int l15 = lane & 15, lg = lane >> 4;
-  f32x4 sinv[4], ds[4];
-#pragma unroll
-  for (int df = 0; df < 4; ++df) {
-    ds[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) sinv[df][e] = in.s[df][e] != 0.f ? __builtin_amdgcn_rcpf(in.s[df][e]) * fu.xs : 0.f;
-  }
-  f32x4 outv[4][2];
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    const bool valid = row0 + 16 * f + l15 < T;
-    f32x4 n[4], sg[4];
-    float dot = 0.f;
-#pragma unroll
-    for (int df = 0; df < 4; ++df) {
-      const bf16x4 xb = __builtin_bit_cast(bf16x4, in.xr[hk][f][df]);
-      n[df] = (f32x4){(float)xb[0], (float)xb[1], (float)xb[2], (float)xb[3]} * sinv[df];
-      if (valid) ds[df] += g[df][f] * n[df];
-      sg[df] = g[df][f] * in.s[df];
-      dot += sg[df][0] * n[df][0] + sg[df][1] * n[df][1] + sg[df][2] * n[df][2] + sg[df][3] * n[df][3];
-    }
-    dot += __shfl_xor(dot, 16, 64);
-    dot += __shfl_xor(dot, 32, 64);
-#pragma unroll
-    for (int df = 0; df < 4; ++df) outv[df][f] = (sg[df] - n[df] * dot) * in.rn[hk][f];
-  }
-  if (row0 < T)
-    store_tile32x64(outv, scr, fu.out + ((size_t)b * T + row0) * fu.ld + h * 64, (size_t)fu.ld, T - row0, lane);
-#pragma unroll
-  for (int df = 0; df < 4; ++df)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float v = ds[df][e];
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
-      v += __shfl_xor(v, 4, 64);
-      v += __shfl_xor(v, 8, 64);
-      if (l15 == 0) red_vw[df * 16 + 4 * lg + e] = v;
-    }
-}
-
-template <bool FUSE>
-__global__ __launch_bounds__(128) void attn_bwd_dkv_asm_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
-                                                               const bf16* __restrict__ kh, const bf16* __restrict__ vh,
-                                                               const float* __restrict__ delta, float scale, float qpre,
-                                                               bf16* __restrict__ dkh, bf16* __restrict__ dvh, int H, int Tq,
-                                                               int Tk, QkFuse fu) {
-  // tile ring (3 x DKV_SLOT), then 2 x 32 KiB of accumulators (wave-private: a wave's store scratch stays inside its own
-  // half), + 1 KiB for the four partial rows of the sqk gradient
-  __shared__ __attribute__((aligned(16))) char lds[2 * 32768 + 1024];
-  static_assert(3 * DKV_SLOT <= 2 * 32768, "the ring must fit the hand-over area");
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = (int)uni32((unsigned)(tid >> 6));
-  const int l15 = lane & 15, lg = lane >> 4;
-  int bh, tile_;
-  const int ntile = (Tk + 127) / 128;
-  work_of(ntile, bh, tile_);
-  const int b = bh / H, h = bh % H;
-  const int k0 = tile_ * 128 + wid * 64;
-  const int BH = gridDim.x / ntile;
-  const int nt = (Tq + TKV - 1) / TKV;
-  const int nvalid_last = Tq - (nt - 1) * TKV;
-  const unsigned ldg = (unsigned)(H * D * 2);
-  // per-lane operands of the asm statement
-  const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
-  const unsigned voff_q0 = (unsigned)(wid * 8 + r8) * ROWB + (unsigned)chunk * 16u;
-  const unsigned voff_g0 = (unsigned)(wid * 8 + r8) * ldg + (unsigned)chunk * 16u;
-  unsigned rows_last = 0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int row = i * 16 + wid * 8 + r8;
-    row = row < nvalid_last ? row : nvalid_last - 1;
-    rows_last |= (unsigned)row << (8 * i);
-  }
-  unsigned kvoff[4];
-#pragma unroll
-  for (int f = 0; f < 4; ++f) {
-    int k = k0 + 16 * f + l15;
-    k = k < Tk ? k : Tk - 1;
-    k = k < 0 ? 0 : k;
-    kvoff[f] = (unsigned)(k * D + lg * 8) * 2u;
-  }
-  const unsigned a0 = (unsigned)swz_off(l15, lg), a1 = (unsigned)swz_off(l15, 4 + lg);
-  unsigned tro[4];
-#pragma unroll
-  for (int df = 0; df < 4; ++df)
-    tro[df] = (unsigned)(swz_off(4 * lg + (l15 >> 2), 2 * df + ((l15 & 3) >> 1)) + ((l15 & 1) << 3));
-  const unsigned pack0 = a0 | (a1 << 16), pack1 = (unsigned)(lg * 16) | (tro[0] << 16), pack2 = tro[1] | (tro[2] << 16),
-                 pack3 = tro[3];
-  const unsigned ring = lds_addr(&lds[0]);
-  const unsigned dump = ring + (unsigned)wid * 32768u + (unsigned)lane * 16u;
-  const unsigned long long s_q = uni64(qh + (size_t)bh * Tq * D);
-  const unsigned long long s_g = uni64(dout + (size_t)b * Tq * (H * D) + h * D);
-  const unsigned long long s_l = uni64(delta + ((size_t)BH + bh) * Tq);   // -lse * log2(e), written by the dq kernel
-  const unsigned long long s_d = uni64(delta + (size_t)bh * Tq);          // -delta
-  const unsigned long long s_k = uni64(kh + (size_t)bh * Tk * D);
-  const unsigned long long s_v = uni64(vh + (size_t)bh * Tk * D);
-  const unsigned s_nt = uni32((unsigned)nt), s_ldg = uni32(ldg), s_ring = uni32(ring), s_nvl = uni32((unsigned)nvalid_last);
-  const unsigned s_act = uni32(k0 < Tk ? 1u : 0u), s_wofs = uni32((unsigned)wid * 1024u);
-  asm volatile(NVIT_ATTN_DKV_ASM_BODY
-               :
-               : "s"(s_q), "s"(s_g), "s"(s_l), "s"(s_d), "s"(s_k), "s"(s_v), "s"(s_nt), "s"(s_ldg), "s"(s_ring), "s"(s_nvl),
-                 "s"(s_act), "s"(s_wofs), "v"(voff_q0), "v"(voff_g0), "v"(rows_last), "v"((unsigned)chunk * 16u),
-                 "v"((unsigned)lane * 4u), "v"(kvoff[0]), "v"(kvoff[1]), "v"(kvoff[2]), "v"(kvoff[3]), "v"(pack0), "v"(pack1),
-                 "v"(pack2), "v"(pack3), "v"(dump)
-               : NVIT_ATTN_DKV_ASM_CLOBBERS);
-#ifdef NVIT_TMP_NOEPI
-  if (Tq > 0) return;
-#endif
-  // (no workgroup barrier here: a wave reads back only what it wrote itself, and its own s_waitcnt lgkmcnt(0) covered that)
-  const bool wave_active = k0 < Tk;
-  QkRowsIn rin;
-  if constexpr (FUSE) qk_rows_load(rin, kh + (size_t)bh * Tk * D, fu, k0, Tk, H, b, h, lane);   // under the read-back below
-  f32x4 dk[4][4], dv[4][4];   // [df][key frag]
-  char* mine = &lds[0] + wid * 32768;
-  if (wave_active) {
-#pragma unroll
-    for (int df = 0; df < 4; ++df)
-#pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        dk[df][f] = *reinterpret_cast<const f32x4*>(mine + lane * 16 + (df * 4 + f) * 1024);
-        dv[df][f] = *reinterpret_cast<const f32x4*>(mine + lane * 16 + (16 + df * 4 + f) * 1024);
-      }
-  }
-  float* red = reinterpret_cast<float*>(&lds[0] + 2 * 32768);
-  const float dks = scale / qpre;   // d/d(k_hat) = scale * dS^T q_hat, and the Q tiles hold qpre * q_hat
-#pragma unroll
-  for (int hk = 0; hk < 2; ++hk) {
-    const int vw = 2 * wid + hk, k0h = k0 + 32 * hk;
-    f32x4 gk[4][2], gv[4][2];
-#pragma unroll
-    for (int df = 0; df < 4; ++df)
-#pragma unroll
-      for (int ff = 0; ff < 2; ++ff) {
-        gk[df][ff] = dk[df][2 * hk + ff] * dks;
-        gv[df][ff] = dv[df][2 * hk + ff];
-      }
-    char* scr = mine + hk * 4096;   // inside this wave's own hand-over area (already read back: DS ops of a wave are ordered)
-    if constexpr (FUSE) {
-      if (k0h < Tk)
-        store_tile32x64(gv, scr, fu.out_v + ((size_t)b * Tk + k0h) * fu.ld + h * 64, (size_t)fu.ld, Tk - k0h, lane);
-      __builtin_amdgcn_wave_barrier();
-      qk_bwd_rows(gk, rin, hk, fu, k0h, Tk, b, h, lane, scr + 8192, red + vw * 64);
-    } else {
-      if (k0h < Tk) {
-        store_tile32x64(gk, scr, dkh + ((size_t)bh * Tk + k0h) * D, (size_t)D, Tk - k0h, lane);
-        __builtin_amdgcn_wave_barrier();
-        store_tile32x64(gv, scr + 8192, dvh + ((size_t)bh * Tk + k0h) * D, (size_t)D, Tk - k0h, lane);
-      }
-    }
-  }
-  if constexpr (FUSE) {
-    __syncthreads();
-    if (threadIdx.x < 64) {
-      const float t = red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x];
-      fu.part[((size_t)b * ntile + tile_) * (H * 64) + h * 64 + threadIdx.x] = t;
-    }
-  }
-}
-
-// ---- the two-waves-per-SIMD form of the hand-placed loop (gen/gen_attn_dkv32_asm.py): the geometry of the compiler-built
-// kernel (4 waves x 32 keys, 256 registers per wave, two workgroups per CU: one workgroup's prologue / epilogue runs under
-// the other's tile loop), the tile loop software-pipelined by the generator.
+// The geometry of the compiler-built kernel (4 waves x 32 keys, 256 registers per wave, two workgroups per CU: one
+// workgroup's prologue / epilogue runs under the other's tile loop), the tile loop software-pipelined by the generator.
+// (A one-wave-per-SIMD form with 64 keys per wave was built as well - tools/probes/gen_attn_dkv64_asm.py, bit-exact too:
+// its tile loop is 1.57x faster per key, but with one wave per SIMD nothing hides a workgroup's prologue and epilogue,
+// 14 of its 31 us, and the kernel ends up 7-13 % slower than the compiler-built one.)
 #include "attn_dkv32_asm.inc"
 
 template <bool FUSE>
@@ -1270,7 +1079,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm32_kernel(const bf16* 
   }
 }
 
-int g_attn_dkv_asm = -1;   // -1: read NVIT_ATTN_DKV_ASM on first use (default on)
+int g_attn_dkv_asm = -1;   // -1: read NVIT_ATTN_DKV_ASM on first use (0: compiler-built kernel; default 1)
 bool use_dkv_asm(float scale, float qpre) {
   if (g_attn_dkv_asm < 0) {
     const char* e = getenv("NVIT_ATTN_DKV_ASM");
@@ -1311,16 +1120,9 @@ int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const v
   return NVIT_OK;
 }
 
-// resident workgroups per CU of the hand-placed dK/dV kernel as the occupancy query sees it (diagnostic)
-extern "C" int nvit_attn_dkv_asm_occupancy(void) {
-  int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, attn_bwd_dkv_asm_kernel<true>, 128, 0) != hipSuccess) return -1;
-  return n;
-}
-
 // (experiments / tests) 1: hand-placed dK/dV main loop where it applies (default), 0: the compiler-built kernel
 extern "C" int nvit_set_attn_dkv_asm(int on) {
-  g_attn_dkv_asm = on < 0 ? 0 : on;   // 0 compiler-built, 1 one wave per SIMD (64 keys per wave), 2 two waves per SIMD (32 keys)
+  g_attn_dkv_asm = on ? 1 : 0;
   return NVIT_OK;
 }
 
@@ -1341,11 +1143,8 @@ int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, c
                      (const bf16*)kh, (const bf16*)vh, lse, (const bf16*)o, delta, scale, qpre, (bf16*)nullptr, H, Tq, Tk,
                      fq);
   NVIT_CHECK_LAUNCH("attn_bwd_dq_mfma_fused");
-  if (use_dkv_asm(scale, qpre) && g_attn_dkv_asm == 2)
+  if (use_dkv_asm(scale, qpre))
     hipLaunchKernelGGL(attn_bwd_dkv_asm32_kernel<true>, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
-                       (const bf16*)kh, (const bf16*)vh, delta, scale, qpre, (bf16*)nullptr, (bf16*)nullptr, H, Tq, Tk, fk);
-  else if (use_dkv_asm(scale, qpre))
-    hipLaunchKernelGGL(attn_bwd_dkv_asm_kernel<true>, gk, dim3(128), 0, s, (const bf16*)dout, (const bf16*)qh,
                        (const bf16*)kh, (const bf16*)vh, delta, scale, qpre, (bf16*)nullptr, (bf16*)nullptr, H, Tq, Tk, fk);
   else
     hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,

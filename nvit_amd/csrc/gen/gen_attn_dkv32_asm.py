@@ -20,6 +20,7 @@ usage: python3 gen_attn_dkv32_asm.py > ../attn_dkv32_asm.inc
 import os
 
 PROBE = set(filter(None, os.environ.get("GEN_PROBE", "").split(",")))
+OPT = set(filter(None, os.environ.get("GEN_OPT", "").split(",")))   # tuning experiments (results stay exact)
 
 SLOT = 2 * 8192 + 512      # Q tile | dO tile | -lse[64] | -delta[64]   (= DKV_SLOT of attn_mfma.hip)
 NSLOT = 3
@@ -311,7 +312,16 @@ def step(j, do_m1=True, do_m2=True, row_next=None, tr_this=None, dma=(), pre_row
                 e(ins)
     blk = list(pre_rows)
     if row_next is not None and not nolds:
-        blk += row_reads(row_next)
+        rr = row_reads(row_next)
+        if "earlyrows" in OPT and not pre_rows and m1:
+            # fragments that only the ks0 products read (a[qq][0], gg[qq][0], -lse, -delta) go out behind the 4th M1 MFMA
+            early = [r for i, r in enumerate(rr) if i % 6 in (0, 2, 4, 5)]
+            late = [r for i, r in enumerate(rr) if i % 6 in (1, 3)]
+            ke = len(m2) + 3
+            after[ke] = after.get(ke, []) + early
+            blk += late
+        else:
+            blk += rr
     k1 = len(mf) - 1
     for k, atom in (dma_after or {}).items():
         kk = min(k, len(mf) - 1) if mf else 0

@@ -730,3 +730,44 @@ def test_rmsnorm_module_fwd_bwd(C):
     assert (out.detach().cpu().double() - ref.detach()).abs().max().item() < 2e-6
     assert (xg.grad.cpu().double() - xd.grad).abs().max().item() < 5e-6
     assert (mod.weight.grad.cpu().double() - wd.grad).abs().max().item() < 2e-5 * max(1.0, wd.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,T", [(2, 2, 64), (1, 2, 200), (2, 3, 784), (1, 1, 16), (2, 2, 49), (1, 2, 833)])
+def test_attn_bwd_dkv_hand_placed_loop_is_bit_exact(B, H, T):
+    """The generated-assembly main loop of the dK/dV kernel (nvit_amd/csrc/gen/gen_attn_dkv32_asm.py) against the
+    compiler-built kernel on the fused backward entry point (pre-scaled q, as the training path calls it): dq | dk | dv and
+    the sqk partial sums must be IDENTICAL, bit for bit - full and ragged tiles (T = 16, 49, 200, 784, 833), key blocks with
+    idle waves, one and several (batch, head) pairs."""
+    from nvit_amd import _lib
+    from nvit_amd._lib import BF16
+    ops = ops_()
+    lib = _lib.load()
+    d_, dv_ = 64, dev()
+    C, M = H * d_, B * T
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    rn = lambda *s: torch.randn(*s, generator=g)
+    sqk = ((1.0 / 32) * (1.0 + 0.05 * torch.tanh(rn(C)))).to(dv_)
+    se = (sqk.cpu() * 32.0).reshape(1, H, 1, d_)
+    qpre = ops.attn_q_prescale(d_)
+    qs = (se * torch.nn.functional.normalize(rn(B, H, T, d_), dim=-1) * qpre).bfloat16().to(dv_)
+    k = (se * torch.nn.functional.normalize(rn(B, H, T, d_), dim=-1)).bfloat16().to(dv_)
+    v = (rn(B, H, T, d_) * 0.05).bfloat16().to(dv_)
+    gt = (rn(M, C) * 1e-3).bfloat16().to(dv_)
+    rq, rk = (1.0 + rn(M, H).abs() * 0.1).to(dv_), (1.0 + rn(M, H).abs() * 0.1).to(dv_)
+    scale = math.sqrt(d_)
+    o, lse = ops.attn_fwd(BF16, 1, qs, k, v, scale, sqk, 32.0, q_prescale=qpre)
+    outs = []
+    try:
+        for mode in (0, 1):
+            lib.nvit_set_attn_dkv_asm(mode)
+            dqkv = torch.zeros(M, 3 * C, device=dv_, dtype=torch.bfloat16)
+            pq, pk = ops.attn_bwd_qknorm(gt, qs, k, v, o, lse, scale, rq, rk, sqk, 32.0, dqkv, 3 * C, dqkv[:, C:], dqkv[:, 2 * C:],
+                                         3 * C, q_prescale=qpre)
+            torch.cuda.synchronize()
+            outs.append((dqkv.clone(), pq.clone(), pk.clone()))
+    finally:
+        lib.nvit_set_attn_dkv_asm(1)
+    (a, pqa, pka), (b, pqb, pkb) = outs
+    assert torch.isfinite(b.float()).all() and a[:, C:].float().abs().max().item() > 0
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    assert torch.equal(pqa, pqb) and torch.equal(pka, pkb)

@@ -6,14 +6,13 @@ cd "$(dirname "$0")/../nvit_amd/csrc"
 make -j8 >/dev/null
 for spec in "$@"; do
   tag=${spec%%:*}; probes=${spec#*:}
+  opts=""; case "$probes" in opt=*) opts=${probes#opt=}; probes="";; esac
   rm -rf build_dkv && mkdir -p build_dkv
   for f in core gemm gemm_p gemm_tn_p kohonen rowops weights optim attn_ref misc xgmi patch_embed; do cp -p build/$f.o build_dkv/$f.o; done
-  GEN_PROBE=$probes python3 gen/gen_attn_dkv_asm.py > attn_dkv_asm.inc
-  GEN_PROBE=$probes python3 gen/gen_attn_dkv32_asm.py > attn_dkv32_asm.inc
+  GEN_PROBE=$probes GEN_OPT=$opts python3 gen/gen_attn_dkv32_asm.py > attn_dkv32_asm.inc
   make BUILD=build_dkv OUT=../libnvit_hip.so.dkv_$tag EXTRA="$DKV_EXTRA" >/dev/null
   echo "built libnvit_hip.so.dkv_$tag ($probes)"
 done
-python3 gen/gen_attn_dkv_asm.py > attn_dkv_asm.inc
 python3 gen/gen_attn_dkv32_asm.py > attn_dkv32_asm.inc
 rm -rf build_dkv
 make -j8 >/dev/null

@@ -14,7 +14,14 @@ into 8 groups g = (32-query half, key fragment); a software pipeline runs M1(g+1
 crosses a step boundary and every instruction of a step can sit in any MFMA gap; LDS fragment reads run one 32-query half
 ahead into a second register set; the Q/dO tiles arrive by LDS-DMA two tiles ahead (one barrier per tile).
 
-usage: python3 gen_attn_dkv_asm.py > ../attn_dkv_asm.inc
+PROBE RECORD (round 4), not part of libnvit_hip.so: the wrapper kernel (attn_bwd_dkv_asm_kernel: 128 threads, 64 KiB + 1 KiB of
+LDS, HIP prologue / epilogue around this statement) is in the tree at commit 13407bb.  Measured there (MI355X, B*H = 1536,
+T = 784): bit-exact with the compiler-built kernel on every shape tried; tile loop 2 700 cycles per 64x64 tile against 4 660
+for the compiler-built kernel's two 64x32 wave tiles (1.57x), but 6.8 us of prologue and 7.4 us of epilogue per workgroup
+sit unhidden on a SIMD that hosts one wave (31 us per workgroup in all against 29.5), so the kernel is 7-13 % SLOWER than
+the compiler-built one.  The two-waves-per-SIMD form (nvit_amd/csrc/gen/gen_attn_dkv32_asm.py) is the product.
+
+usage: python3 gen_attn_dkv64_asm.py > attn_dkv_asm.inc
 """
 import os
 import sys
