@@ -448,28 +448,47 @@ struct QkFuse {
   float xs;           // the saved x_hat rows carry an extra factor 1/xs (pre-scaled q): multiply by xs before use
 };
 
-__device__ __forceinline__ void qk_bwd_epilogue(f32x4 (&g)[4][2], const bf16* xh_bh, const QkFuse& fu, int row0, int T,
-                                                int H, int b, int h, int lane, int wid, char* lds0, int tile,
-                                                int ntile) {
-  // lds0: the (now idle) tile ring; bytes [4096*wid, +4096) = this wave's store scratch, [16384, +1024) = column sums
-  const int l15 = lane & 15, lg = lane >> 4;
-  float* red = reinterpret_cast<float*>(lds0 + 16384);
-  // every global load of the epilogue goes out first (saved unit-direction rows, 1/norm, scale)
+// What the epilogue reads from global memory (saved unit-direction rows, 1/norm, per-channel scale): requested as early as
+// the caller can - behind the tile loop, before the accumulators are even in place - so that the fetch latency runs under the
+// value-gradient store instead of in front of the arithmetic.
+struct QkEpiLoads {
   uint2 xr[2][4];
   float rn[2];
+  f32x4 s[4];
+};
+__device__ __forceinline__ void qk_bwd_epilogue_loads(QkEpiLoads& L, const bf16* xh_bh, const QkFuse& fu, int row0, int T, int H,
+                                                      int b, int h, int lane) {
+  const int l15 = lane & 15, lg = lane >> 4;
 #pragma unroll
   for (int f = 0; f < 2; ++f) {
     const int row = row0 + 16 * f + l15;
     const int rc = row < T ? row : T - 1;
 #pragma unroll
     for (int df = 0; df < 4; ++df)
-      xr[f][df] = *reinterpret_cast<const uint2*>(xh_bh + (size_t)rc * 64 + df * 16 + 4 * lg);
-    rn[f] = fu.rn[((size_t)b * T + rc) * H + h];
+      L.xr[f][df] = *reinterpret_cast<const uint2*>(xh_bh + (size_t)rc * 64 + df * 16 + 4 * lg);
+    L.rn[f] = fu.rn[((size_t)b * T + rc) * H + h];
   }
+#pragma unroll
+  for (int df = 0; df < 4; ++df) L.s[df] = *reinterpret_cast<const f32x4*>(fu.sqk + h * 64 + df * 16 + 4 * lg);
+}
+
+// v + (v of the lane the DPP control CTRL names): a row-internal exchange on the VALU, no LDS round trip
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+  return v + __builtin_bit_cast(float, o);
+}
+
+__device__ __forceinline__ void qk_bwd_epilogue(f32x4 (&g)[4][2], const QkEpiLoads& L, const QkFuse& fu, int row0, int T,
+                                                int H, int b, int h, int lane, int wid, char* lds0, int tile,
+                                                int ntile) {
+  // lds0: the (now idle) tile ring; bytes [4096*wid, +4096) = this wave's store scratch, [16384, +1024) = column sums
+  const int l15 = lane & 15, lg = lane >> 4;
+  float* red = reinterpret_cast<float*>(lds0 + 16384);
   f32x4 s[4], sinv[4], ds[4];
 #pragma unroll
   for (int df = 0; df < 4; ++df) {
-    s[df] = *reinterpret_cast<const f32x4*>(fu.sqk + h * 64 + df * 16 + 4 * lg) * fu.c_q;
+    s[df] = L.s[df] * fu.c_q;
     ds[df] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 4; ++e) sinv[df][e] = s[df][e] != 0.f ? __builtin_amdgcn_rcpf(s[df][e]) * fu.xs : 0.f;   // 1 ulp
@@ -482,7 +501,7 @@ __device__ __forceinline__ void qk_bwd_epilogue(f32x4 (&g)[4][2], const bf16* xh
     float dot = 0.f;
 #pragma unroll
     for (int df = 0; df < 4; ++df) {
-      const bf16x4 xb = __builtin_bit_cast(bf16x4, xr[f][df]);
+      const bf16x4 xb = __builtin_bit_cast(bf16x4, L.xr[f][df]);
       n[df] = (f32x4){(float)xb[0], (float)xb[1], (float)xb[2], (float)xb[3]} * sinv[df];
       if (valid) ds[df] += g[df][f] * n[df];
       sg[df] = g[df][f] * s[df];
@@ -491,22 +510,28 @@ __device__ __forceinline__ void qk_bwd_epilogue(f32x4 (&g)[4][2], const bf16* xh
     dot += __shfl_xor(dot, 16, 64);
     dot += __shfl_xor(dot, 32, 64);
 #pragma unroll
-    for (int df = 0; df < 4; ++df) outv[df][f] = (sg[df] - n[df] * dot) * rn[f];
+    for (int df = 0; df < 4; ++df) outv[df][f] = (sg[df] - n[df] * dot) * L.rn[f];
   }
   if (row0 < T)
     store_tile32x64(outv, lds0 + wid * 4096, fu.out + ((size_t)b * T + row0) * fu.ld + h * 64, (size_t)fu.ld, T - row0, lane);
-  // column sums over this workgroup's 128 rows: 16 lanes (l15) -> 4 waves -> one partial row
+  // column sums over this workgroup's 128 rows: 16 lanes (l15) -> 4 waves -> one partial row.  The 16-lane step is the
+  // butterfly (lane ^ 1, ^ 2, ^ 4, ^ 8) as DPP row exchanges - quad swaps, then the half-row and the row mirrored, which
+  // pair the same partial sums as the xor pattern does (the bits are those of the butterfly: a + b == b + a) - so it costs
+  // 64 VALU adds and no LDS round trips (as 64 dependent ds_bpermute, each waited for, it was most of this epilogue's
+  // time); every lane ends up with all 16 totals of its row group and stores the one its index names.
+  float pick = 0.f;
 #pragma unroll
   for (int df = 0; df < 4; ++df)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float v = ds[df][e];
-      v += __shfl_xor(v, 1, 64);
-      v += __shfl_xor(v, 2, 64);
-      v += __shfl_xor(v, 4, 64);
-      v += __shfl_xor(v, 8, 64);
-      if (l15 == 0) red[wid * 64 + df * 16 + 4 * lg + e] = v;
+      v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+      v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+      v = dpp_add<0x141>(v);   // row_half_mirror
+      v = dpp_add<0x140>(v);   // row_mirror
+      pick = l15 == df * 4 + e ? v : pick;
     }
+  red[wid * 64 + (l15 >> 2) * 16 + 4 * lg + (l15 & 3)] = pick;
   __syncthreads();
   if (threadIdx.x < 64) {
     const float t = red[threadIdx.x] + red[64 + threadIdx.x] + red[128 + threadIdx.x] + red[192 + threadIdx.x];
@@ -693,7 +718,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
 #pragma unroll
     for (int f = 0; f < 2; ++f) dq[i][f] = dq[i][f] * scale;   // d/d(q_hat): K is not pre-scaled
   if constexpr (FUSE) {
-    qk_bwd_epilogue(dq, qh + (size_t)bh * Tq * D, fu, q0, Tq, H, b, h, lane, wid, &lds[0][0][0], tile_, (Tq + 127) / 128);
+    QkEpiLoads el;
+    qk_bwd_epilogue_loads(el, qh + (size_t)bh * Tq * D, fu, q0, Tq, H, b, h, lane);
+    qk_bwd_epilogue(dq, el, fu, q0, Tq, H, b, h, lane, wid, &lds[0][0][0], tile_, (Tq + 127) / 128);
   } else {
     if (wave_active)
       store_tile32x64(dq, &lds[0][0][0] + wid * 4096, dqh + ((size_t)bh * Tq + q0) * D, (size_t)D, Tq - q0, lane);
@@ -950,7 +977,9 @@ __global__ __launch_bounds__(256, DKV_WAVES) void attn_bwd_dkv_mfma_kernel(const
     if (wave_active)
       store_tile32x64(dv, scr, fu.out_v + ((size_t)b * Tk + k0) * fu.ld + h * 64, (size_t)fu.ld, Tk - k0, lane);
     __builtin_amdgcn_wave_barrier();
-    qk_bwd_epilogue(dk, kh + (size_t)bh * Tk * D, fu, k0, Tk, H, b, h, lane, wid, &lds[0], tile_, (Tk + 127) / 128);
+    QkEpiLoads el;
+    qk_bwd_epilogue_loads(el, kh + (size_t)bh * Tk * D, fu, k0, Tk, H, b, h, lane);
+    qk_bwd_epilogue(dk, el, fu, k0, Tk, H, b, h, lane, wid, &lds[0], tile_, (Tk + 127) / 128);
   } else {
     if (wave_active) {
       store_tile32x64(dk, scr, dkh + ((size_t)bh * Tk + k0) * D, (size_t)D, Tk - k0, lane);
@@ -985,7 +1014,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm32_kernel(const bf16* 
                                                                   const bf16* __restrict__ kh, const bf16* __restrict__ vh,
                                                                   const float* __restrict__ delta, float scale, float qpre,
                                                                   bf16* __restrict__ dkh, bf16* __restrict__ dvh, int H,
-                                                                  int Tq, int Tk, QkFuse fu) {
+                                                                  int Tq, int Tk, const float* fu_rn, const float* fu_sqk,
+                                                                  float fu_cq, bf16* fu_out, bf16* fu_outv, int fu_ld,
+                                                                  float* fu_part, float fu_xs) {
+  // (the q/k-normalise operands arrive as scalars and the QkFuse is put together BEHIND the loop: taken by value as one
+  //  struct, part of it is parked in LDS from the first instruction on and the address of that slot lives across the loop
+  //  statement - one register too many for two waves per SIMD)
   __shared__ __attribute__((aligned(16))) char lds[4 * 16384];   // tile ring (3 x DKV_SLOT), then 4 x 16 KiB of accumulators
   static_assert(3 * DKV_SLOT <= 4 * 16384, "the ring must fit the hand-over area");
   const int tid = threadIdx.x;
@@ -1046,7 +1080,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm32_kernel(const bf16* 
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));
   lane = tid2 & 63;
+  const QkFuse fu{fu_rn, fu_sqk, fu_cq, fu_out, fu_outv, fu_ld, fu_part, fu_xs};
   const bool wave_active = k0 < Tk;
+  QkEpiLoads el;
+  if constexpr (FUSE) qk_bwd_epilogue_loads(el, kh + (size_t)bh * Tk * D, fu, k0, Tk, H, b, h, lane);
   f32x4 dk[4][2], dv[4][2];
   if (wave_active) {
     const char* mine = &lds[0] + wid * 16384 + lane * 16;
@@ -1069,7 +1106,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm32_kernel(const bf16* 
     if (wave_active)
       store_tile32x64(dv, scr, fu.out_v + ((size_t)b * Tk + k0) * fu.ld + h * 64, (size_t)fu.ld, Tk - k0, lane);
     __builtin_amdgcn_wave_barrier();
-    qk_bwd_epilogue(dk, kh + (size_t)bh * Tk * D, fu, k0, Tk, H, b, h, lane, wid, &lds[0], tile_, ntile);
+    qk_bwd_epilogue(dk, el, fu, k0, Tk, H, b, h, lane, wid, &lds[0], tile_, ntile);
   } else {
     if (wave_active) {
       store_tile32x64(dk, scr, dkh + ((size_t)bh * Tk + k0) * D, (size_t)D, Tk - k0, lane);
@@ -1145,7 +1182,8 @@ int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, c
   NVIT_CHECK_LAUNCH("attn_bwd_dq_mfma_fused");
   if (use_dkv_asm(scale, qpre))
     hipLaunchKernelGGL(attn_bwd_dkv_asm32_kernel<true>, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
-                       (const bf16*)kh, (const bf16*)vh, delta, scale, qpre, (bf16*)nullptr, (bf16*)nullptr, H, Tq, Tk, fk);
+                       (const bf16*)kh, (const bf16*)vh, delta, scale, qpre, (bf16*)nullptr, (bf16*)nullptr, H, Tq, Tk, fk.rn,
+                       fk.sqk, fk.c_q, fk.out, fk.out_v, fk.ld, fk.part, fk.xs);
   else
     hipLaunchKernelGGL(attn_bwd_dkv_mfma_kernel<true>, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
                        (const bf16*)kh, (const bf16*)vh, lse, delta, scale, qpre, (bf16*)nullptr, (bf16*)nullptr, H, Tq,

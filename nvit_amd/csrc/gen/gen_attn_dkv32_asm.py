@@ -23,7 +23,9 @@ PROBE = set(filter(None, os.environ.get("GEN_PROBE", "").split(",")))
 OPT = set(filter(None, os.environ.get("GEN_OPT", "").split(",")))   # tuning experiments (results stay exact)
 
 SLOT = 2 * 8192 + 512      # Q tile | dO tile | -lse[64] | -delta[64]   (= DKV_SLOT of attn_mfma.hip)
-NSLOT = 3
+RING4 = "ring4" in OPT     # 4-slot ring: the fetch of tile t+2 is spread over steps 0..2 of tile t (it may overwrite the slot of
+                           # tile t-2 before this tile's barrier), instead of bunched into step 3 behind the barrier
+NSLOT = 4 if RING4 else 3
 NDMA = 6                   # DMA wave-instructions per wave per tile
 
 OP = dict(qbase=0, gbase=1, lbase=2, dbase=3, kbase=4, vbase=5, nt=6, ldg=7, ring=8, nvalid_last=9, active=10, wofs=11,
@@ -49,6 +51,22 @@ V_TR = 128                                     # ga[4] (16) qa[4] (16): dO^T / Q
 V_END = 160
 S_B2 = 70                                      # 70:71 second-piece base
 A_DK, A_DV, A_KF, A_VF, A_END = 0, 32, 64, 80, 96
+
+# GEN_PROBE=stamps (tools/probes/attn_dkv_stamps.hip only): s_memtime stamps kept in s72..s82 and written out by lane 0
+# behind the accumulator dump, 16 dwords per wave at operand 24.  The stamps of the barrier block are consumed at the next
+# lgkmcnt(0) the loop has anyway (scalar-memory returns count on lgkmcnt), so the loop's waits stay what they are.
+STAMPS = "stamps" in PROBE
+INLOOP = STAMPS and "inloop" in PROBE      # also stamp the per-tile waits (three more s_memtime per tile)
+S_SB = 72            # 72..77: three 64-bit stamps in flight (prologue: entry / landed / loop entry; barrier block: before
+                     # vmcnt / after vmcnt / after s_barrier; end: drained / last barrier / dumped)
+S_T0 = 78            # 78..80: low words of the prologue stamps
+S_ACC_VM, S_ACC_BAR = 81, 82
+S_STAMP_END = 83
+
+
+def stamp(i):
+    if STAMPS:
+        e(f"s_memtime s[{S_SB + 2 * (i % 3)}:{S_SB + 2 * (i % 3) + 1}]")
 
 out = []
 
@@ -165,10 +183,14 @@ def dma_atoms(last):
     # the two 256-byte rows of row constants: wave 0 fetches -lse, wave 1 -delta (the waits are vmcnt(0), so the waves need
     # not issue the same number of loads)
     uid = len(out) * 1000 + len(atoms) + (500 if last else 0)
-    atoms.append([f"s_cmp_lg_u32 s{S_WOFS}, 0", f"s_cbranch_scc1 .Lnol_{uid}_%="] + pre_l +
+    sel_l = [f"s_bitcmp0_b32 s{S_WOFS}, 10", f"s_cbranch_scc0 .Lnol_{uid}_%="] if RING4 else \
+            [f"s_cmp_lg_u32 s{S_WOFS}, 0", f"s_cbranch_scc1 .Lnol_{uid}_%="]
+    sel_d = [f"s_bitcmp1_b32 s{S_WOFS}, 10", f"s_cbranch_scc0 .Lnod_{uid}_%="] if RING4 else \
+            [f"s_cmp_lg_u32 s{S_WOFS}, 1024", f"s_cbranch_scc1 .Lnod_{uid}_%="]
+    atoms.append(sel_l + pre_l +
                  [f"s_add_u32 s{S_TMP}, s{S_SLOTD}, 16384", f"s_mov_b32 m0, s{S_TMP}", "s_nop 0",
                   f"global_load_lds_dword {vl}, s[{S_L}:{S_L + 1}]", f".Lnol_{uid}_%=:"])
-    atoms.append([f"s_cmp_lg_u32 s{S_WOFS}, 1024", f"s_cbranch_scc1 .Lnod_{uid}_%="] + pre_l +
+    atoms.append(sel_d + pre_l +
                  [f"s_add_u32 s{S_TMP}, s{S_SLOTD}, 16640", f"s_mov_b32 m0, s{S_TMP}", "s_nop 0",
                   f"global_load_lds_dword {vl}, s[{S_D}:{S_D + 1}]", f".Lnod_{uid}_%=:"])
     atoms.append([f"s_add_u32 s{S_Q}, s{S_Q}, 8192", f"s_addc_u32 s{S_Q + 1}, s{S_Q + 1}, 0",
@@ -236,7 +258,7 @@ def tr_address_atoms():
             f"v_add_u32_e32 v{V_RT + 3}, s{S_SLOTT}, %{p3}"]
 
 
-def place(mf, va, after=None, dma=(), v_from=0, v_keep=3):
+def place(mf, va, after=None, dma=(), v_from=0, v_keep=3, dma_keep=0):
     """Emit the MFMAs of a step with its VALU work spread over the gaps from MFMA v_from on; after[i] = instructions that
     follow MFMA i at once (fragment reads behind the last MFMA that uses the registers they overwrite); DMA atoms spread
     over all gaps."""
@@ -254,7 +276,7 @@ def place(mf, va, after=None, dma=(), v_from=0, v_keep=3):
             while vi < want:
                 e(va[vi])
                 vi += 1
-        wd = (len(dma) * (i + 1)) // nm
+        wd = min(len(dma), (len(dma) * (i + 1) + nm - dma_keep - 1) // max(nm - dma_keep, 1)) if dma_keep else (len(dma) * (i + 1)) // nm
         while di < wd:
             for ins in dma[di]:
                 e(ins)
@@ -274,7 +296,12 @@ def place(mf, va, after=None, dma=(), v_from=0, v_keep=3):
                 e(ins)
 
 
-def step(j, do_m1=True, do_m2=True, row_next=None, tr_this=None, dma=(), pre_rows=(), dma_after=None):
+def stamp_sums():
+    return [f"s_sub_u32 s{S_TMP2}, s{S_SB + 2}, s{S_SB}", f"s_add_u32 s{S_ACC_VM}, s{S_ACC_VM}, s{S_TMP2}",
+            f"s_sub_u32 s{S_TMP2}, s{S_SB + 4}, s{S_SB + 2}", f"s_add_u32 s{S_ACC_BAR}, s{S_ACC_BAR}, s{S_TMP2}"]
+
+
+def step(j, do_m1=True, do_m2=True, row_next=None, tr_this=None, dma=(), pre_rows=(), dma_after=None, sums=False):
     """Step j (0..3) of a tile: group (half = j // 2, key fragment f = j % 2).  Order inside a step: M2(g-1) first - its last
     MFMA frees the transposed fragments, whose successors are requested at once - then M1(g+1), behind whose last MFMA the
     next row fragments are requested; V(g) fills the gaps from the 4th MFMA on (its inputs come from the M1 products at the
@@ -293,10 +320,13 @@ def step(j, do_m1=True, do_m2=True, row_next=None, tr_this=None, dma=(), pre_row
         if m2:
             e("s_waitcnt lgkmcnt(12)")
         if m1:
+            extra = stamp_sums() if (sums and INLOOP) else []
             if m2:
-                after[len(m2) - 1] = ["s_waitcnt lgkmcnt(0)"]
+                after[len(m2) - 1] = ["s_waitcnt lgkmcnt(0)"] + extra
             else:
                 e("s_waitcnt lgkmcnt(0)")
+                for ins in extra:
+                    e(ins)
         for k, atom in (dma_after or {}).items():
             kk = min(k, len(mf) - 1) if mf else 0
             after[kk] = after.get(kk, []) + list(atom)
@@ -332,17 +362,24 @@ def step(j, do_m1=True, do_m2=True, row_next=None, tr_this=None, dma=(), pre_row
         else:
             for ins in blk:
                 e(ins)
-    place(mf, va, after, dma, v_from=1)
+    place(mf, va, after, dma, v_from=1, dma_keep=1 if (pre_rows and dma) else 0)
 
 
-def barrier_block(tag):
-    """Tile t+1 has landed (its DMA is the only vector-memory work in flight) and every wave is done with tile t-1."""
+def barrier_block(tag, inflight=0):
+    """Tile t+1 has landed (all vector-memory work but the `inflight` youngest operations - the fetch of tile t+2 with the
+    4-slot ring - is its DMA) and every wave is done with tile t-1."""
     save = out[:]
     del out[:]
-    e("s_waitcnt vmcnt(0)")
+    if INLOOP:
+        e(f"s_memtime s[{S_SB}:{S_SB + 1}]")
+    e(f"s_waitcnt vmcnt({inflight})")
+    if INLOOP:
+        e(f"s_memtime s[{S_SB + 2}:{S_SB + 3}]")
     next_slot(S_TMP, S_SLOTC)
     emit_fixup("loop" + tag, 1)
     e("s_barrier")
+    if INLOOP:
+        e(f"s_memtime s[{S_SB + 4}:{S_SB + 5}]")
     next_slot(S_SLOTC, S_SLOTC)
     set_row_addresses()
     blk = out[:]
@@ -358,12 +395,36 @@ def second_half(variant):
     # behind it: all of it in the gaps of step 3
     step(2, row_next=0, tr_this=1, pre_rows=barrier_block(variant))
     e(f"; step 3 ({variant})")
-    step(3, dma=atoms)
+    step(3, dma=atoms, sums=True)
+
+
+def tile_ring4(variant):
+    """One whole tile with the 4-slot ring: the fetch of tile t+2 (variant F: a full tile, L: the ragged last one, N: none left)
+    goes out over steps 0..2 - ahead of this tile's barrier: its slot is that of tile t-2 - and the barrier waits for all but
+    those NDMA_WAVE operations."""
+    atoms = [] if variant == "N" else dma_atoms(variant == "L")
+    n = len(atoms)
+    c0, c1, c2 = atoms[:(n + 2) // 3], atoms[(n + 2) // 3:(2 * n + 2) // 3], atoms[(2 * n + 2) // 3:]
+    e(f"; tile ({variant}) step 0")
+    step(0, row_next=1, tr_this=0, dma=c0)
+    e(f"; step 1")
+    step(1, dma=c1)
+    e(f"; step 2")
+    step(2, row_next=0, tr_this=1, dma=c2, pre_rows=barrier_block(variant, 0 if variant == "N" else NDMA_WAVE))
+    e(f"; step 3")
+    step(3, sums=True)
+
+
+NDMA_WAVE = 5   # vector-memory operations per wave per tile with ring4 (4 x 1 KiB of Q / dO + one row-constant load)
 
 
 def emit():
     P = OP
     e(f"s_mov_b32 s{S_M0}, m0")
+    stamp(0)
+    if STAMPS:
+        for r in (S_ACC_VM, S_ACC_BAR):
+            e(f"s_mov_b32 s{r}, 0")
     e(f"s_mov_b64 s[{S_Q}:{S_Q + 1}], %{P['qbase']}")
     e(f"s_mov_b64 s[{S_G}:{S_G + 1}], %{P['gbase']}")
     e(f"s_mov_b64 s[{S_L}:{S_L + 1}], %{P['lbase']}")
@@ -399,9 +460,15 @@ def emit():
     for i in range(16):
         e(f"v_mov_b32_e32 v{V_P + i}, 0")
     e("s_waitcnt vmcnt(0)")
+    stamp(1)
     e(f"s_mov_b32 s{S_TMP}, s{S_RING}")
     emit_fixup("pro", 0)
     e("s_barrier")
+    stamp(2)
+    if STAMPS:
+        e("s_waitcnt lgkmcnt(0)")
+        for i in range(3):
+            e(f"s_mov_b32 s{S_T0 + i}, s{S_SB + 2 * i}")
     e(f"s_cmp_eq_u32 s{S_FLAGS}, 0")
     e("s_cbranch_scc1 .Lfeed_only_%=")
     set_row_addresses()
@@ -414,11 +481,28 @@ def emit():
     e(f"s_cmp_lt_u32 s{S_TMP}, s{S_NT}")
     e("s_cbranch_scc0 .Llast_tile_%=")
     e(".Ltile_loop_%=:")
-    e("; step 0")
-    step(0, row_next=1, tr_this=0)
-    e("; step 1")
-    step(1)
-    if "nodma" in PROBE:
+    if RING4:
+        e(f"s_cmp_lt_u32 s{S_TD}, s{S_NT}")
+        e("s_cbranch_scc0 .Lt_none_%=")
+        e(f"s_add_u32 s{S_TMP2}, s{S_TD}, 1")
+        e(f"s_cmp_eq_u32 s{S_TMP2}, s{S_NT}")
+        e("s_cbranch_scc1 .Lt_last_%=")
+        tile_ring4("F")
+        e("s_branch .Lh2_done_%=")
+        e(".Lt_last_%=:")
+        tile_ring4("L")
+        e("s_branch .Lh2_done_%=")
+        e(".Lt_none_%=:")
+        tile_ring4("N")
+        e(".Lh2_done_%=:")
+    else:
+        e("; step 0")
+        step(0, row_next=1, tr_this=0)
+        e("; step 1")
+        step(1)
+    if RING4:
+        pass
+    elif "nodma" in PROBE:
         second_half("N")
     else:
         e(f"s_cmp_lt_u32 s{S_TD}, s{S_NT}")
@@ -456,12 +540,33 @@ def emit():
     for m in m2_atoms(1, 1):
         e(m)
     e(".Ldrained_%=:")
+    stamp(3)
     e("s_nop 15")
     e("s_nop 15")
     e("s_barrier")
+    stamp(4)
     for i in range(16):
         e(f"ds_write_b128 %{P['dump']}, {ar(i * 4)} offset:{i * 1024}")
     e("s_waitcnt lgkmcnt(0)")
+    if STAMPS:
+        stamp(5)
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_mov_b64 s[{S_SAVE}:{S_SAVE + 1}], exec")
+        e("s_mov_b64 exec, 1")
+        e(f"s_getreg_b32 s{S_TMP}, hwreg(HW_REG_HW_ID)")          # wave 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13
+        e(f"s_getreg_b32 s{S_TMP2}, hwreg(HW_REG_XCC_ID)")
+        e(f"s_and_b32 s{S_TMP}, s{S_TMP}, 0xffff")
+        e(f"s_and_b32 s{S_TMP2}, s{S_TMP2}, 15")
+        e(f"s_lshl_b32 s{S_TMP2}, s{S_TMP2}, 16")
+        e(f"s_or_b32 s{S_TMP}, s{S_TMP}, s{S_TMP2}")
+        srcs = [S_T0, S_T0 + 1, S_T0 + 2, S_SB, S_SB + 2, S_SB + 4, S_ACC_VM, S_ACC_BAR, S_T, S_TMP, S_SB + 1, S_SB + 5]
+        for i, r in enumerate(srcs):
+            e(f"v_mov_b32_e32 v{V_ROW + i}, s{r}")
+        e(f"v_mov_b32_e32 v{V_ROW + 15}, 0")
+        for i in range(3):
+            e(f"global_store_dwordx4 v{V_ROW + 15}, {vr(V_ROW + 4 * i)}, %24 offset:{16 * i}")
+        e("s_waitcnt vmcnt(0)")
+        e(f"s_mov_b64 exec, s[{S_SAVE}:{S_SAVE + 1}]")
     e("s_branch .Lend_%=")
     e(".Lfeed_only_%=:")
     e(f"s_add_u32 s{S_TMP}, s{S_T}, 1")
@@ -489,10 +594,11 @@ def emit():
 
 emit()
 print("// GENERATED by gen/gen_attn_dkv32_asm.py - do not edit (regenerate: make -C nvit_amd/csrc gen)")
-print("#define NVIT_ATTN_DKV32_ASM_BODY \\")
+NAME = "NVIT_ATTN_DKV32_STAMPS" if STAMPS else "NVIT_ATTN_DKV32_ASM"
+print(f"#define {NAME}_BODY \\")
 for line in out:
     print(f'  "{line}\\n\\t" \\')
 print('  ""')
-clob = [f'"v{i}"' for i in list(range(16, 25)) + list(range(V_ROW, V_END))] + [f'"a{i}"' for i in range(A_END)] + [f'"s{i}"' for i in range(40, 72)] + ['"vcc"', '"memory"']
-print("#define NVIT_ATTN_DKV32_ASM_CLOBBERS " + ", ".join(clob))
+clob = [f'"v{i}"' for i in list(range(16, 25)) + list(range(V_ROW, V_END))] + [f'"a{i}"' for i in range(A_END)] + [f'"s{i}"' for i in range(40, S_STAMP_END if STAMPS else 72)] + ['"vcc"', '"memory"']
+print(f"#define {NAME}_CLOBBERS " + ", ".join(clob))
 print(f"// instructions: {sum(1 for l in out if not l.startswith(';') and not l.endswith(':'))}")
