@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
-"""Generator of the hand-placed main loop of the attention backward dK/dV kernel (gfx950), TWO waves per SIMD form.
+"""Generator of the hand-placed main loop of the attention backward dK/dV kernel (gfx950), PING-PONG form: a 512-thread
+workgroup = two independent halves of 4 waves x 32 keys (each half its own (batch, head, key block), its own tile ring);
+the two waves of a SIMD belong to different halves and alternate, separated by workgroup barriers, between a COMPUTE
+segment (32 MFMA with the softmax-backward VALU work in their gaps, operands in registers) and a LOAD segment (the 28
+fragment reads of the next half tile, the LDS-DMA pieces of the tile after next) - matrix work beside memory work.
+Measured reason (in-kernel stamps): two matrix-heavy waves on one SIMD do not overlap - with two
+independent 4-wave workgroups per CU the two tile loops take the time of running them one after the other.
 
-Writes attn_dkv32_asm.inc: ONE inline-asm string (the whole tile loop of attn_bwd_dkv_asm32_kernel in attn_mfma.hip) plus
-its clobber list.  Reference semantics: the dK/dV half of the backward of F.scaled_dot_product_attention as the reference
-calls it (/root/reference/nvit/model.py:121-124); arithmetic, operand layouts and accumulation order are those of the
-compiler-built attn_bwd_dkv_mfma_kernel, against which this one is bit-exact.
+Writes attn_dkv_pp_asm.inc: ONE inline-asm string (the whole tile loop of attn_bwd_dkv_pp_kernel in attn_mfma.hip) plus its
+clobber list.  Arithmetic, operand layouts and accumulation order are those of the compiler-built attn_bwd_dkv_mfma_kernel
+(reference semantics: the dK/dV half of the backward of F.scaled_dot_product_attention as the reference calls it,
+/root/reference/nvit/model.py:121-124); bit-exact against it.
 
-Same geometry as the compiler-built kernel (a workgroup = 4 waves x 32 keys, two workgroups per CU, so one workgroup's
-prologue / epilogue runs under the other's tile loop), but the tile loop is a software pipeline placed by this script:
-the work of a 64-query tile is cut into 4 groups g = (32-query half, key fragment); every step issues M1(g+1) [S and dP
-products, 8 MFMA], V(g) [exp2, p*(dP-delta), bf16 packs: 24 VALU] and M2(g-1) [dV and dK products, 8 MFMA], so every
-dependency crosses a step boundary.  Fragment registers are single-buffered (256 registers per wave): the row fragments of
-the next half are requested right behind the last MFMA that reads the current ones, the transposed fragments likewise,
-and land under the rest of the step.  128 registers per wave sit in the accumulation half (dK / dV accumulators, K / V
-fragments, nothing the compiler ever sees); the accumulators return through LDS.
+Program of a half (t = tile, h = 32-query half, f = key fragment; groups g = (h, f) in the order (0,0) (0,1) (1,0) (1,1)):
+  step 0: M2(prev tile (1,1)) V(0,0) M1(0,1) | BAR | LOAD a: transposed(t,0) rows(t,1) 3 DMA pieces | BAR |
+  step 1: M2(0,0) V(0,1) M1(1,0);  step 2: M2(0,1) V(1,0) M1(1,1);  wait for tile t+1 | BAR |
+  LOAD b: transposed(t,1) rows(t+1,0) 2 DMA pieces | BAR | step 3: M2(1,0) V(1,1) M1(next (0,0))
+The second half runs the same program one barrier later, so its compute segments (steps 3+0, steps 1+2) fall beside the
+first half's load segments and vice versa.
 
-usage: python3 gen_attn_dkv32_asm.py > ../attn_dkv32_asm.inc
+usage: python3 gen_attn_dkv_pp_asm.py > ../attn_dkv_pp_asm.inc
 """
 import os
 
@@ -23,9 +27,9 @@ PROBE = set(filter(None, os.environ.get("GEN_PROBE", "").split(",")))
 OPT = set(filter(None, os.environ.get("GEN_OPT", "").split(",")))   # tuning experiments (results stay exact)
 
 SLOT = 2 * 8192 + 512      # Q tile | dO tile | -lse[64] | -delta[64]   (= DKV_SLOT of attn_mfma.hip)
-RING4 = "ring4" in OPT     # 4-slot ring: the fetch of tile t+2 is spread over steps 0..2 of tile t (it may overwrite the slot of
+RING4 = True   # every wave issues exactly one of the two row-constant loads     # 4-slot ring: the fetch of tile t+2 is spread over steps 0..2 of tile t (it may overwrite the slot of
                            # tile t-2 before this tile's barrier), instead of bunched into step 3 behind the barrier
-NSLOT = 4 if RING4 else 3
+NSLOT = 3
 NDMA = 6                   # DMA wave-instructions per wave per tile
 
 OP = dict(qbase=0, gbase=1, lbase=2, dbase=3, kbase=4, vbase=5, nt=6, ldg=7, ring=8, nvalid_last=9, active=10, wofs=11,
@@ -219,60 +223,6 @@ def dma_atoms(last):
     return atoms
 
 
-def emit_dma(tag):
-    e(f"s_add_u32 s{S_TMP2}, s{S_TD}, 1")
-    e(f"s_cmp_eq_u32 s{S_TMP2}, s{S_NT}")
-    e(f"s_cbranch_scc1 .Ldma_last_{tag}_%=")
-    for a in dma_atoms(False):
-        for i in a:
-            e(i)
-    e(f"s_branch .Ldma_done_{tag}_%=")
-    e(f".Ldma_last_{tag}_%=:")
-    for a in dma_atoms(True):
-        for i in a:
-            e(i)
-    e(f".Ldma_done_{tag}_%=:")
-
-
-def emit_fixup(tag, plus):
-    e(f"s_add_u32 s{S_TMP2}, s{S_T}, {plus + 1}")
-    e(f"s_cmp_eq_u32 s{S_TMP2}, s{S_NT}")
-    e(f"s_cbranch_scc0 .Lfix_skip_{tag}_%=")
-    e(f"s_cmp_lt_u32 s{S_NVL}, 64")
-    e(f"s_cbranch_scc0 .Lfix_skip_{tag}_%=")
-    e(f"v_lshrrev_b32_e32 v{V_TMP}, 2, %{OP['lane4']}")
-    e(f"v_cmp_ge_u32_e64 s[{S_EXEC}:{S_EXEC + 1}], v{V_TMP}, s{S_NVL}")
-    e(f"s_and_saveexec_b64 s[{S_SAVE}:{S_SAVE + 1}], s[{S_EXEC}:{S_EXEC + 1}]")
-    e(f"v_add_u32_e32 v{V_TMP}, s{S_TMP}, %{OP['lane4']}")
-    e(f"v_mov_b32_e32 v{V_TMP2}, 0xff800000")
-    e(f"ds_write_b32 v{V_TMP}, v{V_TMP2} offset:16384")
-    e(f"s_mov_b64 exec, s[{S_SAVE}:{S_SAVE + 1}]")
-    e("s_waitcnt lgkmcnt(0)")
-    e(f".Lfix_skip_{tag}_%=:")
-
-
-def next_slot(dst, src):
-    e(f"s_add_u32 s{dst}, s{src}, {SLOT}")
-    e(f"s_cmp_ge_u32 s{dst}, s{S_RINGEND}")
-    e(f"s_cselect_b32 s{dst}, s{S_RING}, s{dst}")
-
-
-def set_row_addresses():
-    p0, p1 = OP['lds_pack0'], OP['lds_pack0'] + 1
-    e(f"v_and_b32_e32 v{V_TMP}, 0xffff, %{p0}")
-    e(f"v_add_u32_e32 v{V_RA0}, s{S_SLOTC}, v{V_TMP}")
-    e(f"v_lshrrev_b32_e32 v{V_TMP}, 16, %{p0}")
-    e(f"v_add_u32_e32 v{V_RA1}, s{S_SLOTC}, v{V_TMP}")
-    e(f"v_and_b32_e32 v{V_TMP}, 0xffff, %{p1}")
-    e(f"v_add_u32_e32 v{V_RN}, s{S_SLOTC}, v{V_TMP}")
-
-
-def tr_address_atoms():
-    p1, p2, p3 = OP['lds_pack0'] + 1, OP['lds_pack0'] + 2, OP['lds_pack0'] + 3
-    return [f"v_lshrrev_b32_e32 v{V_TMP}, 16, %{p1}", f"v_add_u32_e32 v{V_RT}, s{S_SLOTT}, v{V_TMP}",
-            f"v_and_b32_e32 v{V_TMP}, 0xffff, %{p2}", f"v_add_u32_e32 v{V_RT + 1}, s{S_SLOTT}, v{V_TMP}",
-            f"v_lshrrev_b32_e32 v{V_TMP}, 16, %{p2}", f"v_add_u32_e32 v{V_RT + 2}, s{S_SLOTT}, v{V_TMP}",
-            f"v_add_u32_e32 v{V_RT + 3}, s{S_SLOTT}, %{p3}"]
 
 
 def place(mf, va, after=None, dma=(), v_from=0, v_keep=3, dma_keep=0):
@@ -323,159 +273,226 @@ def place(mf, va, after=None, dma=(), v_from=0, v_keep=3, dma_keep=0):
                 e(ins)
 
 
-def stamp_sums():
-    return [f"s_sub_u32 s{S_TMP2}, s{S_SB + 2}, s{S_SB}", f"s_add_u32 s{S_ACC_VM}, s{S_ACC_VM}, s{S_TMP2}",
-            f"s_sub_u32 s{S_TMP2}, s{S_SB + 4}, s{S_SB + 2}", f"s_add_u32 s{S_ACC_BAR}, s{S_ACC_BAR}, s{S_TMP2}"]
+
+def emit_seq(atoms):
+    for a in atoms:
+        for i in a:
+            e(i)
 
 
-def step(j, do_m1=True, do_m2=True, row_next=None, tr_this=None, dma=(), pre_rows=(), dma_after=None, sums=False):
-    """Step j (0..3) of a tile: group (half = j // 2, key fragment f = j % 2).  Order inside a step: M2(g-1) first - its last
-    MFMA frees the transposed fragments, whose successors are requested at once - then M1(g+1), behind whose last MFMA the
-    next row fragments are requested; V(g) fills the gaps from the 4th MFMA on (its inputs come from the M1 products at the
-    end of the previous step).
-    row_next: half index (0/1) whose row fragments are requested behind M1 (None: none);  tr_this: half whose transposed
-    fragments are requested behind M2;  pre_rows: instructions between M1 and the row reads (the barrier block)."""
-    f = j % 2
+def emit_fixup(tag, plus):
+    """-inf into the -lse entries of the rows past the end of the ragged last tile, if tile S_T + plus is that tile
+    (slot base in S_TMP); every wave does it behind its own vmcnt wait, before the barrier that publishes the tile."""
+    e(f"s_add_u32 s{S_TMP2}, s{S_T}, {plus + 1}")
+    e(f"s_cmp_eq_u32 s{S_TMP2}, s{S_NT}")
+    e(f"s_cbranch_scc0 .Lfix_skip_{tag}_%=")
+    e(f"s_cmp_lt_u32 s{S_NVL}, 64")
+    e(f"s_cbranch_scc0 .Lfix_skip_{tag}_%=")
+    e(f"v_lshrrev_b32_e32 v{V_TMP}, 2, %{OP['lane4']}")
+    e(f"v_cmp_ge_u32_e64 s[{S_EXEC}:{S_EXEC + 1}], v{V_TMP}, s{S_NVL}")
+    e(f"s_and_saveexec_b64 s[{S_SAVE}:{S_SAVE + 1}], s[{S_EXEC}:{S_EXEC + 1}]")
+    e(f"v_add_u32_e32 v{V_TMP}, s{S_TMP}, %{OP['lane4']}")
+    e(f"v_mov_b32_e32 v{V_TMP2}, 0xff800000")
+    e(f"ds_write_b32 v{V_TMP}, v{V_TMP2} offset:16384")
+    e(f"s_mov_b64 exec, s[{S_SAVE}:{S_SAVE + 1}]")
+    e("s_waitcnt lgkmcnt(0)")
+    e(f".Lfix_skip_{tag}_%=:")
+
+
+def next_slot(dst, src):
+    e(f"s_add_u32 s{dst}, s{src}, {SLOT}")
+    e(f"s_cmp_ge_u32 s{dst}, s{S_RINGEND}")
+    e(f"s_cselect_b32 s{dst}, s{S_RING}, s{dst}")
+
+
+S_SLOTN = S_SLOTC          # slot of tile t+1 (rows of the next tile's first half are read from it)
+# S_SLOTT: slot of tile t
+
+
+def row_addresses(slot):
+    p0, p1 = OP['lds_pack0'], OP['lds_pack0'] + 1
+    e(f"v_and_b32_e32 v{V_TMP}, 0xffff, %{p0}")
+    e(f"v_add_u32_e32 v{V_RA0}, s{slot}, v{V_TMP}")
+    e(f"v_lshrrev_b32_e32 v{V_TMP}, 16, %{p0}")
+    e(f"v_add_u32_e32 v{V_RA1}, s{slot}, v{V_TMP}")
+    e(f"v_and_b32_e32 v{V_TMP}, 0xffff, %{p1}")
+    e(f"v_add_u32_e32 v{V_RN}, s{slot}, v{V_TMP}")
+
+
+def tr_addresses():
+    p1, p2, p3 = OP['lds_pack0'] + 1, OP['lds_pack0'] + 2, OP['lds_pack0'] + 3
+    for ins in [f"v_lshrrev_b32_e32 v{V_TMP}, 16, %{p1}", f"v_add_u32_e32 v{V_RT}, s{S_SLOTT}, v{V_TMP}",
+                f"v_and_b32_e32 v{V_TMP}, 0xffff, %{p2}", f"v_add_u32_e32 v{V_RT + 1}, s{S_SLOTT}, v{V_TMP}",
+                f"v_lshrrev_b32_e32 v{V_TMP}, 16, %{p2}", f"v_add_u32_e32 v{V_RT + 2}, s{S_SLOTT}, v{V_TMP}",
+                f"v_add_u32_e32 v{V_RT + 3}, s{S_SLOTT}, %{p3}"]:
+        e(ins)
+
+
+NOLDS = "nolds" in PROBE
+NODMA = "nodma" in PROBE
+N_A = 3    # vector-memory operations of a tile's fetch issued in load segment a (the other 2 in b)
+
+
+def bar():
+    e("s_barrier")
+
+
+def compute_step(j, do_m1=True, do_m2=True):
     m1 = m1_atoms((j + 1) % 2, (j + 1) % 2) if (do_m1 and "nom1" not in PROBE) else []
     m2 = m2_atoms((j - 1) % 2, (j - 1) % 2) if (do_m2 and "nom2" not in PROBE) else []
     va = [] if "novalu" in PROBE else (v_sched(j % 2, j % 2) if "vsched" in OPT else v_atoms(j % 2, j % 2))
-    nolds = "nolds" in PROBE
-    mf = m2 + m1
-    after = {}
-    if f == 1:
-        # fragment reads of the previous step: 16 transposed (needed by M2 now), then 12 rows (needed by M1)
-        if m2:
-            e("s_waitcnt lgkmcnt(12)")
-        if m1:
-            extra = stamp_sums() if (sums and INLOOP) else []
-            if m2:
-                after[len(m2) - 1] = ["s_waitcnt lgkmcnt(0)"] + extra
-            else:
-                e("s_waitcnt lgkmcnt(0)")
-                for ins in extra:
-                    e(ins)
-        for k, atom in (dma_after or {}).items():
-            kk = min(k, len(mf) - 1) if mf else 0
-            after[kk] = after.get(kk, []) + list(atom)
-        place(mf, va, after, dma, v_from=1)
-        return
-    k2 = len(m2) - 1
-    if tr_this is not None and not nolds and "spreadtr" in OPT and k2 == 7:
-        # the transposed fragments of d-block df are free once M2's MFMA pair df has issued: request their successors there
-        # instead of all 16 behind the last pair (same order, so the counted waits of the next step hold)
-        rd = tr_reads(tr_this)
-        after[0] = after.get(0, []) + tr_address_atoms()
-        for df in range(4):
-            after[2 * df + 1] = after.get(2 * df + 1, []) + rd[4 * df:4 * df + 4]
-    elif tr_this is not None and not nolds:
-        blk = tr_address_atoms() + tr_reads(tr_this)
-        if k2 >= 0:
-            after[k2] = after.get(k2, []) + blk
-        else:
-            for ins in blk:
-                e(ins)
-    blk = list(pre_rows)
-    if row_next is not None and not nolds:
-        rr = row_reads(row_next)
-        if "earlyrows" in OPT and not pre_rows and m1:
-            # fragments that only the ks0 products read (a[qq][0], gg[qq][0], -lse, -delta) go out behind the 4th M1 MFMA
-            early = [r for i, r in enumerate(rr) if i % 6 in (0, 2, 4, 5)]
-            late = [r for i, r in enumerate(rr) if i % 6 in (1, 3)]
-            ke = len(m2) + 3
-            after[ke] = after.get(ke, []) + early
-            blk += late
-        else:
-            blk += rr
-    k1 = len(mf) - 1
-    for k, atom in (dma_after or {}).items():
-        kk = min(k, len(mf) - 1) if mf else 0
-        after[kk] = after.get(kk, []) + list(atom)
-    if blk:
-        if k1 >= 0:
-            after[k1] = after.get(k1, []) + blk
-        else:
-            for ins in blk:
-                e(ins)
-    place(mf, va, after, dma, v_from=1, dma_keep=1 if (pre_rows and dma) else 0)
+    place(m2 + m1, va, v_from=1)
 
 
-def barrier_block(tag, inflight=0):
-    """Tile t+1 has landed (all vector-memory work but the `inflight` youngest operations - the fetch of tile t+2 with the
-    4-slot ring - is its DMA) and every wave is done with tile t-1."""
-    save = out[:]
-    del out[:]
-    if INLOOP:
-        e(f"s_memtime s[{S_SB}:{S_SB + 1}]")
+def load_a(atoms, rows=True):
+    """transposed fragments of (t, half 0); row fragments of (t, half 1); the first pieces of the fetch of tile t+2"""
+    if not NOLDS:
+        tr_addresses()
+        rr = tr_reads(0)
+        if rows:
+            row_addresses(S_SLOTT)
+            rr = rr + row_reads(1)
+    else:
+        rr = []
+    interleave(rr, atoms)
+
+
+def load_b(atoms, rows=True):
+    """transposed fragments of (t, half 1); row fragments of (t+1, half 0); the rest of the fetch of tile t+2"""
+    if not NOLDS:
+        rr = tr_reads(1)          # (addresses: those of load segment a, same tile)
+        if rows:
+            row_addresses(S_SLOTN)
+            rr = rr + row_reads(0)
+    else:
+        rr = []
+    interleave(rr, atoms)
+
+
+def interleave(reads, atoms):
+    """LDS reads with the DMA atoms spread between them"""
+    atoms = list(atoms)
+    n, k = len(reads), len(atoms)
+    di = 0
+    for i, r in enumerate(reads):
+        e(r)
+        want = (k * (i + 1)) // max(n, 1)
+        while di < want:
+            for ins in atoms[di]:
+                e(ins)
+            di += 1
+    while di < k:
+        for ins in atoms[di]:
+            e(ins)
+        di += 1
+
+
+def split_atoms(atoms):
+    """(segment a, segment b): head + the first N_A vector-memory pieces | the rest + the cursor updates"""
+    if not atoms:
+        return [], []
+    return atoms[:1 + N_A], atoms[1 + N_A:]
+
+
+def wait_next_tile(tag, inflight):
+    """end of steps 1+2: tile t+1 must have landed (this wave's pieces of it) before the barrier that lets load segment b
+    read it; `inflight` = pieces of tile t+2 already issued behind them"""
     e(f"s_waitcnt vmcnt({inflight})")
-    if INLOOP:
-        e(f"s_memtime s[{S_SB + 2}:{S_SB + 3}]")
-    next_slot(S_TMP, S_SLOTC)
-    emit_fixup("loop" + tag, 1)
-    e("s_barrier")
-    if INLOOP:
-        e(f"s_memtime s[{S_SB + 4}:{S_SB + 5}]")
-    next_slot(S_SLOTC, S_SLOTC)
-    set_row_addresses()
-    blk = out[:]
-    del out[:]
-    out.extend(save)
-    return blk
+    e(f"s_mov_b32 s{S_TMP}, s{S_SLOTN}")
+    emit_fixup(tag, 1)
 
 
-def second_half(variant):
-    atoms = [] if variant == "N" else dma_atoms(variant == "L")
-    e(f"; step 2 ({variant})")
-    # the barrier sits behind the last MFMA of step 2; the fetch of tile t+2 overwrites the slot of tile t-1, so it goes out
-    # behind it: all of it in the gaps of step 3
-    step(2, row_next=0, tr_this=1, pre_rows=barrier_block(variant))
-    e(f"; step 3 ({variant})")
-    step(3, dma=atoms, sums=True)
+def tile(variant):
+    atoms = [] if (variant == "N" or NODMA) else dma_atoms(variant == "L")
+    ca, cb = split_atoms(atoms)
+    e(f"; ---- tile ({variant}): step 0")
+    compute_step(0)
+    bar()
+    load_a(ca)
+    bar()
+    e("s_waitcnt lgkmcnt(0)")
+    compute_step(1)
+    compute_step(2)
+    wait_next_tile("t" + variant, N_A if atoms else 0)
+    bar()
+    load_b(cb)
+    bar()
+    e("s_waitcnt lgkmcnt(0)")
+    compute_step(3)
 
 
-def tile_ring4(variant):
-    """One whole tile with the 4-slot ring: the fetch of tile t+2 (variant F: a full tile, L: the ragged last one, N: none left)
-    goes out over steps 0..2 - ahead of this tile's barrier: its slot is that of tile t-2 - and the barrier waits for all but
-    those NDMA_WAVE operations."""
-    atoms = [] if variant == "N" else dma_atoms(variant == "L")
-    n = len(atoms)
-    c0, c1, c2 = atoms[:(n + 2) // 3], atoms[(n + 2) // 3:(2 * n + 2) // 3], atoms[(2 * n + 2) // 3:]
-    e(f"; tile ({variant}) step 0")
-    step(0, row_next=1, tr_this=0, dma=c0)
-    e(f"; step 1")
-    step(1, dma=c1)
-    e(f"; step 2")
-    step(2, row_next=0, tr_this=1, dma=c2, pre_rows=barrier_block(variant, 0 if variant == "N" else NDMA_WAVE))
-    e(f"; step 3")
-    step(3, sums=True)
+def feed_tile(variant):
+    atoms = [] if (variant == "N" or NODMA) else dma_atoms(variant == "L")
+    ca, cb = split_atoms(atoms)
+    bar()
+    emit_seq(ca)
+    bar()
+    wait_next_tile("f" + variant, N_A if atoms else 0)
+    bar()
+    emit_seq(cb)
+    bar()
 
 
-NDMA_WAVE = 5   # vector-memory operations per wave per tile with ring4 (4 x 1 KiB of Q / dO + one row-constant load)
+def variants(fn, tag):
+    """three copies of a tile body, by what is left to fetch: a full tile t+2 (F), the ragged last one (L), nothing (N)"""
+    if NODMA:
+        fn("N")
+        return
+    e(f"s_cmp_lt_u32 s{S_TD}, s{S_NT}")
+    e(f"s_cbranch_scc0 .L{tag}_none_%=")
+    e(f"s_add_u32 s{S_TMP2}, s{S_TD}, 1")
+    e(f"s_cmp_eq_u32 s{S_TMP2}, s{S_NT}")
+    e(f"s_cbranch_scc1 .L{tag}_last_%=")
+    fn("F")
+    e(f"s_branch .L{tag}_done_%=")
+    e(f".L{tag}_last_%=:")
+    fn("L")
+    e(f"s_branch .L{tag}_done_%=")
+    e(f".L{tag}_none_%=:")
+    fn("N")
+    e(f".L{tag}_done_%=:")
+
+
+def emit_dma(tag):
+    e(f"s_add_u32 s{S_TMP2}, s{S_TD}, 1")
+    e(f"s_cmp_eq_u32 s{S_TMP2}, s{S_NT}")
+    e(f"s_cbranch_scc1 .Ldma_last_{tag}_%=")
+    emit_seq(dma_atoms(False))
+    e(f"s_branch .Ldma_done_{tag}_%=")
+    e(f".Ldma_last_{tag}_%=:")
+    emit_seq(dma_atoms(True))
+    e(f".Ldma_done_{tag}_%=:")
+
+
+def advance_tile():
+    e(f"s_mov_b32 s{S_SLOTT}, s{S_SLOTN}")
+    next_slot(S_SLOTN, S_SLOTN)
+    e(f"s_add_u32 s{S_T}, s{S_T}, 1")
 
 
 def emit():
     P = OP
     e(f"s_mov_b32 s{S_M0}, m0")
     stamp(0)
-    if STAMPS:
-        for r in (S_ACC_VM, S_ACC_BAR):
-            e(f"s_mov_b32 s{r}, 0")
+    e(f"s_mov_b32 s{S_NT}, %{P['nt']}")
+    e(f"s_mov_b32 s{S_FLAGS}, %{P['active']}")     # bit 0: this wave has keys; bit 1: this half has a work item; bit 2: second half
+    e(f"s_bitcmp1_b32 s{S_FLAGS}, 1")
+    e("s_cbranch_scc0 .Lidle_half_%=")
     e(f"s_mov_b64 s[{S_Q}:{S_Q + 1}], %{P['qbase']}")
     e(f"s_mov_b64 s[{S_G}:{S_G + 1}], %{P['gbase']}")
     e(f"s_mov_b64 s[{S_L}:{S_L + 1}], %{P['lbase']}")
     e(f"s_mov_b64 s[{S_D}:{S_D + 1}], %{P['dbase']}")
-    e(f"s_mov_b32 s{S_NT}, %{P['nt']}")
     e(f"s_mov_b32 s{S_LDG}, %{P['ldg']}")
     e(f"s_mov_b32 s{S_RING}, %{P['ring']}")
     e(f"s_mov_b32 s{S_NVL}, %{P['nvalid_last']}")
-    e(f"s_mov_b32 s{S_FLAGS}, %{P['active']}")
     e(f"s_mov_b32 s{S_WOFS}, %{P['wofs']}")
     e(f"s_lshl_b32 s{S_P32}, s{S_LDG}, 5")
     e(f"s_lshl_b32 s{S_T64}, s{S_LDG}, 6")
     e(f"s_add_u32 s{S_RINGEND}, s{S_RING}, {NSLOT * SLOT}")
     e(f"s_mov_b32 s{S_T}, 0")
     e(f"s_mov_b32 s{S_TD}, 0")
-    e(f"s_mov_b32 s{S_SLOTC}, s{S_RING}")
     e(f"s_mov_b32 s{S_SLOTT}, s{S_RING}")
+    e(f"s_add_u32 s{S_SLOTN}, s{S_RING}, {SLOT}")
     e(f"s_mov_b32 s{S_SLOTD}, s{S_RING}")
     emit_dma("p0")
     for f in range(2):
@@ -486,7 +503,6 @@ def emit():
     e("s_cbranch_scc0 .Lno_second_%=")
     emit_dma("p1")
     e(".Lno_second_%=:")
-    # zero: accumulators; the transposed fragments and both packed sets (group -1 multiplies zeros)
     for i in range(64):
         e(f"v_accvgpr_write_b32 a{A_DK + i}, 0")
     for i in range(32):
@@ -497,63 +513,30 @@ def emit():
     stamp(1)
     e(f"s_mov_b32 s{S_TMP}, s{S_RING}")
     emit_fixup("pro", 0)
-    e("s_barrier")
+    bar()                                            # barrier 0: tiles 0 and 1 are in place
     stamp(2)
     if STAMPS:
         e("s_waitcnt lgkmcnt(0)")
         for i in range(3):
             e(f"s_mov_b32 s{S_T0 + i}, s{S_SB + 2 * i}")
-    e(f"s_cmp_eq_u32 s{S_FLAGS}, 0")
-    e("s_cbranch_scc1 .Lfeed_only_%=")
-    set_row_addresses()
+    e(f"s_bitcmp1_b32 s{S_FLAGS}, 0")
+    e("s_cbranch_scc0 .Lfeed_only_%=")
+    row_addresses(S_SLOTT)
     for r in row_reads(0):
         e(r)
     e("s_waitcnt lgkmcnt(0)")
     for m in m1_atoms(0, 0):
         e(m)
+    e(f"s_bitcmp1_b32 s{S_FLAGS}, 2")                # the second half runs one barrier behind the first
+    e("s_cbranch_scc0 .Lno_shift_%=")
+    bar()
+    e(".Lno_shift_%=:")
     e(f"s_add_u32 s{S_TMP}, s{S_T}, 1")
     e(f"s_cmp_lt_u32 s{S_TMP}, s{S_NT}")
     e("s_cbranch_scc0 .Llast_tile_%=")
     e(".Ltile_loop_%=:")
-    if RING4:
-        e(f"s_cmp_lt_u32 s{S_TD}, s{S_NT}")
-        e("s_cbranch_scc0 .Lt_none_%=")
-        e(f"s_add_u32 s{S_TMP2}, s{S_TD}, 1")
-        e(f"s_cmp_eq_u32 s{S_TMP2}, s{S_NT}")
-        e("s_cbranch_scc1 .Lt_last_%=")
-        tile_ring4("F")
-        e("s_branch .Lh2_done_%=")
-        e(".Lt_last_%=:")
-        tile_ring4("L")
-        e("s_branch .Lh2_done_%=")
-        e(".Lt_none_%=:")
-        tile_ring4("N")
-        e(".Lh2_done_%=:")
-    else:
-        e("; step 0")
-        step(0, row_next=1, tr_this=0)
-        e("; step 1")
-        step(1)
-    if RING4:
-        pass
-    elif "nodma" in PROBE:
-        second_half("N")
-    else:
-        e(f"s_cmp_lt_u32 s{S_TD}, s{S_NT}")
-        e("s_cbranch_scc0 .Lh2_none_%=")
-        e(f"s_add_u32 s{S_TMP2}, s{S_TD}, 1")
-        e(f"s_cmp_eq_u32 s{S_TMP2}, s{S_NT}")
-        e("s_cbranch_scc1 .Lh2_last_%=")
-        second_half("F")
-        e("s_branch .Lh2_done_%=")
-        e(".Lh2_last_%=:")
-        second_half("L")
-        e("s_branch .Lh2_done_%=")
-        e(".Lh2_none_%=:")
-        second_half("N")
-        e(".Lh2_done_%=:")
-    e(f"s_mov_b32 s{S_SLOTT}, s{S_SLOTC}")        # the next tile's transposed fragments come from the slot just switched to
-    e(f"s_add_u32 s{S_T}, s{S_T}, 1")
+    variants(tile, "t")
+    advance_tile()
     e(f"s_add_u32 s{S_TMP}, s{S_T}, 1")
     e(f"s_cmp_lt_u32 s{S_TMP}, s{S_NT}")
     e("s_cbranch_scc1 .Ltile_loop_%=")
@@ -561,23 +544,41 @@ def emit():
     e(f"s_cmp_le_u32 s{S_NVL}, 32")
     e("s_cbranch_scc0 .Llast_full_%=")
     e("; short last tile: its second half contributes exactly nothing (p = 0)")
-    step(0, row_next=None, tr_this=0)
-    step(1, do_m1=False)
+    compute_step(0)
+    bar()
+    load_a([], rows=False)
+    bar()
+    e("s_waitcnt lgkmcnt(0)")
+    compute_step(1, do_m1=False)
     for m in m2_atoms(1, 1):
         e(m)
+    bar()
+    bar()
     e("s_branch .Ldrained_%=")
     e(".Llast_full_%=:")
-    step(0, row_next=1, tr_this=0)
-    step(1)
-    step(2, row_next=None, tr_this=1)
-    step(3, do_m1=False)
+    compute_step(0)
+    bar()
+    load_a([])
+    bar()
+    e("s_waitcnt lgkmcnt(0)")
+    compute_step(1)
+    compute_step(2)
+    bar()
+    load_b([], rows=False)
+    bar()
+    e("s_waitcnt lgkmcnt(0)")
+    compute_step(3, do_m1=False)
     for m in m2_atoms(1, 1):
         e(m)
     e(".Ldrained_%=:")
     stamp(3)
+    e(f"s_bitcmp1_b32 s{S_FLAGS}, 2")                # the first half waits one barrier for the second
+    e("s_cbranch_scc1 .Lno_tail_%=")
+    bar()
+    e(".Lno_tail_%=:")
     e("s_nop 15")
     e("s_nop 15")
-    e("s_barrier")
+    bar()                                            # every wave of the workgroup is done with its rings
     stamp(4)
     for i in range(16):
         e(f"ds_write_b128 %{P['dump']}, {ar(i * 4)} offset:{i * 1024}")
@@ -587,7 +588,7 @@ def emit():
         e("s_waitcnt lgkmcnt(0)")
         e(f"s_mov_b64 s[{S_SAVE}:{S_SAVE + 1}], exec")
         e("s_mov_b64 exec, 1")
-        e(f"s_getreg_b32 s{S_TMP}, hwreg(HW_REG_HW_ID)")          # wave 3:0, SIMD 5:4, CU 11:8, SH 12, SE 15:13
+        e(f"s_getreg_b32 s{S_TMP}, hwreg(HW_REG_HW_ID)")
         e(f"s_getreg_b32 s{S_TMP2}, hwreg(HW_REG_XCC_ID)")
         e(f"s_and_b32 s{S_TMP}, s{S_TMP}, 0xffff")
         e(f"s_and_b32 s{S_TMP2}, s{S_TMP2}, 15")
@@ -602,33 +603,52 @@ def emit():
         e("s_waitcnt vmcnt(0)")
         e(f"s_mov_b64 exec, s[{S_SAVE}:{S_SAVE + 1}]")
     e("s_branch .Lend_%=")
+    # ---- a wave without keys in a half that has work: feeds the ring, keeps every barrier
     e(".Lfeed_only_%=:")
+    e(f"s_bitcmp1_b32 s{S_FLAGS}, 2")
+    e("s_cbranch_scc0 .Lfeed_no_shift_%=")
+    bar()
+    e(".Lfeed_no_shift_%=:")
     e(f"s_add_u32 s{S_TMP}, s{S_T}, 1")
     e(f"s_cmp_lt_u32 s{S_TMP}, s{S_NT}")
-    e("s_cbranch_scc0 .Lfeed_done_%=")
+    e("s_cbranch_scc0 .Lfeed_last_%=")
     e(".Lfeed_loop_%=:")
-    e("s_waitcnt vmcnt(0)")
-    next_slot(S_TMP, S_SLOTC)
-    emit_fixup("feed", 1)
-    e("s_barrier")
-    next_slot(S_SLOTC, S_SLOTC)
-    e(f"s_cmp_lt_u32 s{S_TD}, s{S_NT}")
-    e("s_cbranch_scc0 .Lfeed_nodma_%=")
-    emit_dma("feed")
-    e(".Lfeed_nodma_%=:")
-    e(f"s_add_u32 s{S_T}, s{S_T}, 1")
+    variants(feed_tile, "f")
+    advance_tile()
     e(f"s_add_u32 s{S_TMP}, s{S_T}, 1")
     e(f"s_cmp_lt_u32 s{S_TMP}, s{S_NT}")
     e("s_cbranch_scc1 .Lfeed_loop_%=")
-    e(".Lfeed_done_%=:")
-    e("s_barrier")
+    e(".Lfeed_last_%=:")
+    for i in range(4):
+        bar()
+    e("s_branch .Ltail_bars_%=")
+    # ---- a half without a work item (odd number of items): keeps every barrier
+    e(".Lidle_half_%=:")
+    bar()                                            # barrier 0
+    e(f"s_bitcmp1_b32 s{S_FLAGS}, 2")
+    e("s_cbranch_scc0 .Lidle_no_shift_%=")
+    bar()
+    e(".Lidle_no_shift_%=:")
+    e(f"s_mov_b32 s{S_T}, 0")
+    e(".Lidle_loop_%=:")
+    for i in range(4):
+        bar()
+    e(f"s_add_u32 s{S_T}, s{S_T}, 1")
+    e(f"s_cmp_lt_u32 s{S_T}, s{S_NT}")
+    e("s_cbranch_scc1 .Lidle_loop_%=")
+    e(".Ltail_bars_%=:")
+    e(f"s_bitcmp1_b32 s{S_FLAGS}, 2")
+    e("s_cbranch_scc1 .Ltail_no_%=")
+    bar()
+    e(".Ltail_no_%=:")
+    bar()
     e(".Lend_%=:")
     e(f"s_mov_b32 m0, s{S_M0}")
 
 
 emit()
-print("// GENERATED by gen/gen_attn_dkv32_asm.py - do not edit (regenerate: make -C nvit_amd/csrc gen)")
-NAME = "NVIT_ATTN_DKV32_STAMPS" if STAMPS else "NVIT_ATTN_DKV32_ASM"
+NAME = "NVIT_ATTN_DKV_PP_STAMPS" if STAMPS else "NVIT_ATTN_DKV_PP_ASM"
+print("// GENERATED by gen/gen_attn_dkv_pp_asm.py - do not edit (regenerate: make -C nvit_amd/csrc gen)")
 print(f"#define {NAME}_BODY \\")
 for line in out:
     print(f'  "{line}\\n\\t" \\')

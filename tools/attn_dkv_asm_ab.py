@@ -10,7 +10,7 @@ from nvit_amd._lib import BF16
 dev = torch.device("cuda:0")
 lib = _lib.load()
 d = 64
-MODES = [1]   # 1: the hand-placed main loop (two waves per SIMD x 32 keys), 0: the compiler-built kernel
+MODES = [int(x) for x in os.environ.get("MODES", "1,2").split(",")]   # 0: compiler-built; 1: hand-placed, two 4-wave workgroups per CU; 2: hand-placed, ping-pong halves
 
 
 def make(B, H, T, seed=0):
@@ -90,7 +90,7 @@ if __name__ == "__main__":
         for asm in modes:
             lib.nvit_set_attn_dkv_asm(asm)
             res[asm].append(t_of(bwd, n=12))
-    names = {0: "compiler-built", 1: "hand-placed"}
+    names = {0: "compiler-built", 1: "hand-placed (2 x 4 waves)", 2: "hand-placed ping-pong (8 waves)"}
     for asm in modes:
         ts = sorted(res[asm])
         print(f"backward (dq + dkv), dkv {names[asm]}: median {ts[len(ts) // 2]:7.1f} us  min {ts[0]:7.1f} us")

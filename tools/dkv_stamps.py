@@ -39,7 +39,20 @@ def main(B, H, T):
     nwg = math.ceil(T / 128) * B * H
     stamps = torch.zeros(nwg * 4, 16, device=dev, dtype=torch.int32)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for it in range(5):
+    def cu_span(sn):
+        sn = sn[sn[:, 5] != 0]
+        key = sn[:, 9] & 0xFFF00
+        sp = []
+        for k in np.unique(key):
+            m = key == k
+            base = sn[m, 12][0]
+            ent = ((sn[m, 12] - base + 2 ** 31) & 0xFFFFFFFF) - 2 ** 31
+            ex = ((sn[m, 13] - base + 2 ** 31) & 0xFFFFFFFF) - 2 ** 31
+            sp.append(ex.max() - ent.min())
+        return float(np.median(sp))
+
+    spans_it = []
+    for it in range(9):
         stamps.zero_()
         e0.record()
         rc = fn(p(c["gt"]), p(c["qs"]), p(c["k"]), p(c["v"]), p(delta), c["scale"], p(c["rk"]), p(c["sqk"]), 32.0, c["qpre"],
@@ -47,7 +60,10 @@ def main(B, H, T):
         e1.record()
         assert rc == 0
         torch.cuda.synchronize()
+        spans_it.append(cu_span(stamps.cpu().numpy().astype(np.int64) & 0xFFFFFFFF))
     us = e0.elapsed_time(e1) * 1e3
+    print(f"KERNEL CYCLES (busy span of a CU, median over CUs; the clock-independent figure): per launch "
+          f"{[int(x) for x in spans_it]} -> median {int(np.median(spans_it[2:]))}")
     print(f"stamped kernel: {us:.1f} us; results identical to the product: {bool((dqkv == ref).all().item())}")
     s = stamps.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
     act = s[:, 5] != 0                       # waves that ran the loop (a workgroup's waves past the last key only feed)
