@@ -1120,136 +1120,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm32_kernel(const bf16* 
   }
 }
 
-// ------------------------------------------------------------------------------------------ dK, dV: ping-pong form
-// The same hand-placed arithmetic in a 512-thread workgroup of two independent halves (two work items): the two waves of a
-// SIMD belong to different halves and alternate, barrier by barrier, between a compute segment and a load segment
-// (gen/gen_attn_dkv_pp_asm.py -> attn_dkv_pp_asm.inc; measurements: DESIGN.md section 5, round 4).
-#include "attn_dkv_pp_asm.inc"
-
-template <bool FUSE>
-__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_pp_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ qh,
-                                                                  const bf16* __restrict__ kh, const bf16* __restrict__ vh,
-                                                                  const float* __restrict__ delta, float scale, float qpre,
-                                                                  bf16* __restrict__ dkh, bf16* __restrict__ dvh, int H,
-                                                                  int Tq, int Tk, const float* fu_rn, const float* fu_sqk,
-                                                                  float fu_cq, bf16* fu_out, bf16* fu_outv, int fu_ld,
-                                                                  float* fu_part, float fu_xs, int nitems) {
-  // (the q/k-normalise operands arrive as scalars and the QkFuse is put together BEHIND the loop: taken by value as one
-  //  struct, part of it is parked in LDS from the first instruction on and the address of that slot lives across the loop
-  //  statement - one register too many for two waves per SIMD)
-  // two work items per workgroup: waves 0-3 (half 0) and 4-7 (half 1) each own a (batch, head, key block), a 3-slot tile
-  // ring and, behind the loop, 4 x 16 KiB of accumulator hand-over in their own 64 KiB of LDS
-  __shared__ __attribute__((aligned(16))) char lds_all[2 * 65536];
-  static_assert(3 * DKV_SLOT <= 65536, "a half's ring must fit its 64 KiB");
-  const int tid = threadIdx.x;
-  int lane = tid & 63;
-  const int wid8 = (int)uni32((unsigned)(tid >> 6));
-  const int hid = wid8 >> 2, wid = wid8 & 3;
-  char* lds = lds_all + hid * 65536;
-  const int l15 = lane & 15, lg = lane >> 4;
-  int bh, tile_;
-  const int ntile = (Tk + 127) / 128;
-  const int item0 = 2 * work_index() + hid;
-  const bool item_valid = item0 < nitems;
-  const int item = item_valid ? item0 : nitems - 1;   // (an idle half computes addresses of a real item and touches nothing)
-  bh = item / ntile;
-  tile_ = item - bh * ntile;
-  const int b = bh / H, h = bh % H;
-  const int k0 = tile_ * 128 + wid * 32;
-  const int BH = nitems / ntile;
-  const int nt = (Tq + TKV - 1) / TKV;
-  const int nvalid_last = Tq - (nt - 1) * TKV;
-  const unsigned ldg = (unsigned)(H * D * 2);
-  const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
-  const unsigned voff_q0 = tile_voff(0, ROWB, lane, wid), voff_g0 = tile_voff(0, ldg, lane, wid);
-  unsigned rows_last = 0;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    int row = (i * 4 + wid) * 8 + r8;
-    row = row < nvalid_last ? row : nvalid_last - 1;
-    rows_last |= (unsigned)row << (8 * i);
-  }
-  unsigned kvoff[2];
-#pragma unroll
-  for (int f = 0; f < 2; ++f) {
-    int k = k0 + 16 * f + l15;
-    k = k < Tk ? k : Tk - 1;
-    kvoff[f] = (unsigned)(k * D + lg * 8) * 2u;
-  }
-  const unsigned a0 = (unsigned)swz_off(l15, lg), a1 = (unsigned)swz_off(l15, 4 + lg);
-  unsigned tro[4];
-#pragma unroll
-  for (int df = 0; df < 4; ++df)
-    tro[df] = (unsigned)(swz_off(4 * lg + (l15 >> 2), 2 * df + ((l15 & 3) >> 1)) + ((l15 & 1) << 3));
-  const unsigned pack0 = a0 | (a1 << 16), pack1 = (unsigned)(lg * 16) | (tro[0] << 16), pack2 = tro[1] | (tro[2] << 16),
-                 pack3 = tro[3];
-  const unsigned ring = lds_addr(lds);
-  const unsigned dump = ring + (unsigned)wid * 16384u + (unsigned)lane * 16u;
-  const unsigned long long s_q = uni64(qh + (size_t)bh * Tq * D);
-  const unsigned long long s_g = uni64(dout + (size_t)b * Tq * (H * D) + h * D);
-  const unsigned long long s_l = uni64(delta + ((size_t)BH + bh) * Tq);
-  const unsigned long long s_d = uni64(delta + (size_t)bh * Tq);
-  const unsigned long long s_k = uni64(kh + (size_t)bh * Tk * D);
-  const unsigned long long s_v = uni64(vh + (size_t)bh * Tk * D);
-  const unsigned s_nt = uni32((unsigned)nt), s_ldg = uni32(ldg), s_ring = uni32(ring), s_nvl = uni32((unsigned)nvalid_last);
-  const unsigned s_act = uni32((k0 < Tk && item_valid ? 1u : 0u) | (item_valid ? 2u : 0u) | ((unsigned)hid << 2)), s_wofs = uni32((unsigned)wid * 1024u);
-  asm volatile(NVIT_ATTN_DKV_PP_ASM_BODY
-               :
-               : "s"(s_q), "s"(s_g), "s"(s_l), "s"(s_d), "s"(s_k), "s"(s_v), "s"(s_nt), "s"(s_ldg), "s"(s_ring), "s"(s_nvl),
-                 "s"(s_act), "s"(s_wofs), "v"(voff_q0), "v"(voff_g0), "v"(rows_last), "v"((unsigned)chunk * 16u),
-                 "v"((unsigned)lane * 4u), "v"(kvoff[0]), "v"(kvoff[1]), "v"(pack0), "v"(pack1), "v"(pack2), "v"(pack3),
-                 "v"(dump)
-               : NVIT_ATTN_DKV_PP_ASM_CLOBBERS);
-  // lane-dependent values are formed afresh behind the loop: nothing per-lane has to live across it (16 registers are all the
-  // compiler has there, and what does not fit would be parked in the accumulation half, i.e. cost a wave per SIMD)
-  int tid2 = threadIdx.x;
-  asm volatile("" : "+v"(tid2));
-  lane = tid2 & 63;
-  const QkFuse fu{fu_rn, fu_sqk, fu_cq, fu_out, fu_outv, fu_ld, fu_part, fu_xs};
-  const bool wave_active = k0 < Tk && item_valid;
-  QkEpiLoads el;
-  if constexpr (FUSE) qk_bwd_epilogue_loads(el, kh + (size_t)bh * Tk * D, fu, k0, Tk, H, b, h, lane);   // (clamped rows: safe)
-  f32x4 dk[4][2], dv[4][2];
-  if (wave_active) {
-    const char* mine = lds + wid * 16384 + lane * 16;
-#pragma unroll
-    for (int df = 0; df < 4; ++df)
-#pragma unroll
-      for (int f = 0; f < 2; ++f) {
-        dk[df][f] = *reinterpret_cast<const f32x4*>(mine + (df * 2 + f) * 1024);
-        dv[df][f] = *reinterpret_cast<const f32x4*>(mine + (8 + df * 2 + f) * 1024);
-      }
-  }
-  __syncthreads();   // every wave holds its accumulators: the LDS becomes store scratch (as in the compiler-built kernel)
-  const float dks = scale / qpre;
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int f = 0; f < 2; ++f) dk[i][f] = dk[i][f] * dks;
-  char* scr = lds + wid * 4096;
-  if constexpr (FUSE) {
-    if (wave_active)
-      store_tile32x64(dv, scr, fu.out_v + ((size_t)b * Tk + k0) * fu.ld + h * 64, (size_t)fu.ld, Tk - k0, lane);
-    __builtin_amdgcn_wave_barrier();
-    qk_bwd_epilogue(dk, el, fu, item_valid ? k0 : Tk, Tk, H, b, h, lane, wid, lds, tile_, ntile, (int)threadIdx.x & 255,
-                    item_valid);
-  } else {
-    if (wave_active) {
-      store_tile32x64(dk, scr, dkh + ((size_t)bh * Tk + k0) * D, (size_t)D, Tk - k0, lane);
-      __builtin_amdgcn_wave_barrier();
-      store_tile32x64(dv, scr, dvh + ((size_t)bh * Tk + k0) * D, (size_t)D, Tk - k0, lane);
-    }
-  }
-}
-
-// -1: read NVIT_ATTN_DKV_ASM on first use.  0: compiler-built kernel; 1: hand-placed loop, two independent 4-wave
-// workgroups per CU; 2: hand-placed loop, ping-pong form (one 8-wave workgroup of two halves per CU)
+// -1: read NVIT_ATTN_DKV_ASM on first use.  0: compiler-built kernel; 1 (default): hand-placed loop
 int g_attn_dkv_asm = -1;
-constexpr int DKV_ASM_DEFAULT = 1;
 int dkv_asm_mode(float scale, float qpre) {
   if (g_attn_dkv_asm < 0) {
     const char* e = getenv("NVIT_ATTN_DKV_ASM");
-    g_attn_dkv_asm = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : DKV_ASM_DEFAULT;
+    g_attn_dkv_asm = (e && e[0] == '0') ? 0 : 1;
   }
   const float c2 = scale * LOG2E / qpre;
   return fabsf(c2 - 1.0f) < 1e-6f ? g_attn_dkv_asm : 0;   // the hand-placed loops assume the pre-scaled q (c2 = 1)
@@ -1288,7 +1164,7 @@ int nvit_attn_bwd_mfma(const void* dout, const void* qh, const void* kh, const v
 
 // (experiments / tests) 1: hand-placed dK/dV main loop where it applies (default), 0: the compiler-built kernel
 extern "C" int nvit_set_attn_dkv_asm(int mode) {
-  g_attn_dkv_asm = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
+  g_attn_dkv_asm = mode > 0 ? 1 : 0;
   return NVIT_OK;
 }
 
@@ -1310,12 +1186,7 @@ int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, c
                      fq);
   NVIT_CHECK_LAUNCH("attn_bwd_dq_mfma_fused");
   const int mode = dkv_asm_mode(scale, qpre);
-  if (mode == 2) {
-    const int nitems = (int)gk.x;
-    hipLaunchKernelGGL(attn_bwd_dkv_pp_kernel<true>, dim3((unsigned)((nitems + 1) / 2)), dim3(512), 0, s, (const bf16*)dout,
-                       (const bf16*)qh, (const bf16*)kh, (const bf16*)vh, delta, scale, qpre, (bf16*)nullptr, (bf16*)nullptr, H,
-                       Tq, Tk, fk.rn, fk.sqk, fk.c_q, fk.out, fk.out_v, fk.ld, fk.part, fk.xs, nitems);
-  } else if (mode == 1)
+  if (mode == 1)
     hipLaunchKernelGGL(attn_bwd_dkv_asm32_kernel<true>, gk, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
                        (const bf16*)kh, (const bf16*)vh, delta, scale, qpre, (bf16*)nullptr, (bf16*)nullptr, H, Tq, Tk, fk.rn,
                        fk.sqk, fk.c_q, fk.out, fk.out_v, fk.ld, fk.part, fk.xs);

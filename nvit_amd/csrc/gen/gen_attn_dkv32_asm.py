@@ -20,7 +20,9 @@ usage: python3 gen_attn_dkv32_asm.py > ../attn_dkv32_asm.inc
 import os
 
 PROBE = set(filter(None, os.environ.get("GEN_PROBE", "").split(",")))
-OPT = set(filter(None, os.environ.get("GEN_OPT", "").split(",")))   # tuning experiments (results stay exact)
+# placement options (results stay exact).  Product = ring4,spreadtr,earlyrows: -1.6 % kernel cycles together against none of
+# them (profiles/r04_dkv_cycles_ring4_spread.log); GEN_OPT=none builds without; vsched (one transcendental per MFMA gap): +-0
+OPT = set(filter(None, (os.environ.get("GEN_OPT") or "ring4,spreadtr,earlyrows").split(","))) - {"none"}
 
 SLOT = 2 * 8192 + 512      # Q tile | dO tile | -lse[64] | -delta[64]   (= DKV_SLOT of attn_mfma.hip)
 RING4 = "ring4" in OPT     # 4-slot ring: the fetch of tile t+2 is spread over steps 0..2 of tile t (it may overwrite the slot of

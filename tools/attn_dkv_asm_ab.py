@@ -10,7 +10,7 @@ from nvit_amd._lib import BF16
 dev = torch.device("cuda:0")
 lib = _lib.load()
 d = 64
-MODES = [int(x) for x in os.environ.get("MODES", "1,2").split(",")]   # 0: compiler-built; 1: hand-placed, two 4-wave workgroups per CU; 2: hand-placed, ping-pong halves
+MODES = [int(x) for x in os.environ.get("MODES", "1").split(",")]   # 0: compiler-built; 1: hand-placed (2: the ping-pong probe build of commit 240ec07 only)
 
 
 def make(B, H, T, seed=0):

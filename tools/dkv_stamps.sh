@@ -1,16 +1,12 @@
 #!/bin/bash
 # Builds the stamped variant of the hand-placed dK/dV kernel (build container): nvit_amd/libnvit_hip.so.dkv_stamps =
 # the product objects with attn_mfma.o replaced by tools/probes/attn_dkv_stamps.hip (the product TU + the stamped copy).
-# Read with tools/dkv_stamps.py on the GPU box.      [GEN_PROBE=inloop,nodma,...] [GEN_OPT=ring4,...] [PROBE_ALONE=1] [PROBE_KERNEL=pp] [TAG=_x] bash tools/dkv_stamps.sh   (inloop: also the per-tile waits)
+# Read with tools/dkv_stamps.py on the GPU box.      [GEN_PROBE=inloop,nodma,...] [GEN_OPT=ring4,...] [PROBE_ALONE=1] [TAG=_x] bash tools/dkv_stamps.sh   (inloop: also the per-tile waits)
 set -e
 root="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$root/nvit_amd/csrc"
 make -j8 >/dev/null
-if [ "$PROBE_KERNEL" = pp ]; then
-  GEN_PROBE=stamps${GEN_PROBE:+,$GEN_PROBE} GEN_OPT=$GEN_OPT python3 gen/gen_attn_dkv_pp_asm.py > "$root/tools/probes/attn_dkv_pp_stamps.inc"
-else
-  GEN_PROBE=stamps${GEN_PROBE:+,$GEN_PROBE} GEN_OPT=$GEN_OPT python3 gen/gen_attn_dkv32_asm.py > "$root/tools/probes/attn_dkv32_stamps.inc"
-fi
+GEN_PROBE=stamps${GEN_PROBE:+,$GEN_PROBE} GEN_OPT=$GEN_OPT python3 gen/gen_attn_dkv32_asm.py > "$root/tools/probes/attn_dkv32_stamps.inc"
 python3 "$root/tools/probes/make_dkv_stamps_tu.py"
 rm -rf build_dkv && mkdir -p build_dkv
 objs=""

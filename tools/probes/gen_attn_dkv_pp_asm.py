@@ -19,7 +19,14 @@ Program of a half (t = tile, h = 32-query half, f = key fragment; groups g = (h,
 The second half runs the same program one barrier later, so its compute segments (steps 3+0, steps 1+2) fall beside the
 first half's load segments and vice versa.
 
-usage: python3 gen_attn_dkv_pp_asm.py > ../attn_dkv_pp_asm.inc
+MEASURED, NOT ADOPTED (round 4).  Bit-exact on every shape of the GPU test, but 1.37 M cycles per launch against the 1.14 M
+of the product form (two independent 4-wave workgroups per CU): the loop runs 3 195 cycles per tile PAIR (MFMA alone 2 210,
+VALU +692, LDS reads +379, DMA +158: profiles/r04_dkv_cycles_pingpong_probes.log) against 2 x 1 975 for two stand-alone
+waves, i.e. the alternation buys 19 %, and the workgroup's prologue and epilogue (36 % of its life) are no longer covered by
+a partner workgroup.  The kernel that used this loop (attn_bwd_dkv_pp_kernel, mode 2 of nvit_set_attn_dkv_asm) is in
+commit 240ec07 of this repository: nvit_amd/csrc/attn_mfma.hip there; this generator wrote its attn_dkv_pp_asm.inc.
+
+usage (at that commit): python3 gen_attn_dkv_pp_asm.py > ../../nvit_amd/csrc/attn_dkv_pp_asm.inc
 """
 import os
 
