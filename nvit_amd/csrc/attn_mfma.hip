@@ -441,14 +441,17 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
 // backward kernels: g = dL/dx_hat in the accumulator layout (row = row0 + 16f + l15, d = 16df + 4lg + r).
 // Writes dL/dx (bf16, token-major) and this workgroup's partial sums of dL/d(sqk*c_q) for its head.
 struct QkFuse {
+  // (pointers first, the three 4-byte scalars together: hipcc widens the load of a scalar that is splat into a vector to 16
+  //  bytes; next to a pointer that slice of the struct cannot be kept in registers and is parked in LDS for the whole
+  //  kernel - 16 bytes per lane, flat stores through the reloaded pointer)
   const float* rn;    // [B*T, H] 1/||x|| saved by the forward
   const float* sqk;   // [C]
-  float c_q;
   bf16* out;          // token-major gradient of the projection output: out[(b*T + row)*ld + h*64 + d]
   bf16* out_v;        // (dk/dv kernel only) same for the value projection
-  int ld;
   float* part;        // [B * gridDim.x, C]
+  float c_q;
   float xs;           // the saved x_hat rows carry an extra factor 1/xs (pre-scaled q): multiply by xs before use
+  int ld;
 };
 
 // What the epilogue reads from global memory (saved unit-direction rows, 1/norm, per-channel scale): requested as early as
@@ -1084,7 +1087,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm32_kernel(const bf16* 
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));
   lane = tid2 & 63;
-  const QkFuse fu{fu_rn, fu_sqk, fu_cq, fu_out, fu_outv, fu_ld, fu_part, fu_xs};
+  const QkFuse fu{fu_rn, fu_sqk, fu_out, fu_outv, fu_part, fu_cq, fu_xs, fu_ld};
   const bool wave_active = k0 < Tk;
   QkEpiLoads el;
   if constexpr (FUSE) qk_bwd_epilogue_loads(el, kh + (size_t)bh * Tk * D, fu, k0, Tk, H, b, h, lane);
@@ -1179,8 +1182,8 @@ int nvit_attn_bwd_mfma_fused(const void* dout, const void* qh, const void* kh, c
   NVIT_REQUIRE(o != nullptr && delta != nullptr, "attn_bwd: the attention output and the [2,B,H,Tq] side buffer are required");
   dim3 gq((unsigned)(cdiv(Tq, 128) * B * H)), gk((unsigned)(cdiv(Tk, 128) * B * H));
   NVIT_REQUIRE(qpre > 0.f, "attn_bwd: the q pre-scale must be positive (got %g)", (double)qpre);
-  QkFuse fq{rq, sqk, c_q, (bf16*)dq, nullptr, ldq, part_q, 1.0f / qpre};
-  QkFuse fk{rk, sqk, c_q, (bf16*)dk, (bf16*)dv, ldkv, part_k, 1.0f};
+  QkFuse fq{rq, sqk, (bf16*)dq, nullptr, part_q, c_q, 1.0f / qpre, ldq};
+  QkFuse fk{rk, sqk, (bf16*)dk, (bf16*)dv, part_k, c_q, 1.0f, ldkv};
   hipLaunchKernelGGL(attn_bwd_dq_mfma_kernel<true>, gq, dim3(256), 0, s, (const bf16*)dout, (const bf16*)qh,
                      (const bf16*)kh, (const bf16*)vh, lse, (const bf16*)o, delta, scale, qpre, (bf16*)nullptr, H, Tq, Tk,
                      fq);
