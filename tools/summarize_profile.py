@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     for key in ("gemm_nt_persistent", "gemm_tn_persistent", "gemm_nt_kernel", "gemm_tn_kernel", "attn_fwd_mfma",
-                "attn_bwd_dq_mfma", "attn_bwd_dkv_mfma", "attn_delta", "lerp_fwd", "lerp_bwd", "qknorm_fwd",
+                "attn_bwd_dq_mfma", "attn_bwd_dkv_mfma", "attn_bwd_dkv_asm32", "attn_fwd_ref", "attn_delta", "lerp_fwd", "lerp_bwd", "qknorm_fwd",
                 "qknorm_bwd", "swiglu_fwd", "swiglu_bwd", "colsum_reduce", "colsum_kernel", "slab_reduce", "adamw_renorm", "grad_sqnorm", "renorm",
                 "shadow", "patch_embed", "im2col", "pool", "recon", "cast_kernel", "scale_cols", "FusedAdam", "multi_tensor",
                 "elementwise", "rocclr", "reduce_kernel", "softmax", "nll_loss"):
