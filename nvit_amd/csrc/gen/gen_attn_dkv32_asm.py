@@ -89,8 +89,13 @@ def mfma(d, a, b, c):
     return f"v_mfma_f32_16x16x32_bf16 {d}, {a}, {b}, {c}"
 
 
+MFMA32 = "mfma32" in PROBE   # TIMING ONLY (garbage results): half as many v_mfma_f32_32x32x16_bf16 in place of the 16x16x32
+
+
 def m1_atoms(fn, zbuf):
     R, Z = V_ROW, V_Z + 16 * zbuf
+    if MFMA32:
+        return [f"v_mfma_f32_32x32x16_bf16 {vr(Z, 16)}, {vr(R + 4 * i)}, {ar(A_KF + (fn * 2 + i % 2) * 4)}, {vr(Z, 16)}" for i in range(4)]
     ks0, ks1 = [], []
     for qq in (0, 1):
         z, w = vr(Z + qq * 4), vr(Z + 8 + qq * 4)
@@ -103,6 +108,9 @@ def m1_atoms(fn, zbuf):
 
 def m2_atoms(fp, pbuf):
     P = V_P + 8 * pbuf
+    if MFMA32:
+        return [f"v_mfma_f32_32x32x16_bf16 {ar((A_DV if i % 2 == 0 else A_DK) + 16 * fp, 16)}, {vr(V_TR + 4 * i)}, {vr(P + 4 * (i % 2))}, "
+                f"{ar((A_DV if i % 2 == 0 else A_DK) + 16 * fp, 16)}" for i in range(4)]
     res = []
     for df in range(4):
         dv = ar(A_DV + (df * 2 + fp) * 4)
@@ -290,6 +298,8 @@ def place(mf, va, after=None, dma=(), v_from=0, v_keep=3, dma_keep=0):
         elif len(mf) == 8:
             sched = [va[2 * i] + va[2 * i + 1] for i in range(8)]
         va = [] if sched else [x for gp in va for x in gp]
+    if MFMA32:
+        v_keep = 1
     nv = max(nm - v_from - v_keep, 1)     # the last v_keep gaps stay free: the next step's first MFMAs read what V packs
     vi = di = 0
     dma = list(dma)
