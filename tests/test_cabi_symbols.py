@@ -84,3 +84,32 @@ def test_product_sources_carry_no_probe_switches():
     mk = open(os.path.join(csrc, "Makefile")).read()
     listed = set(re.search(r"^SRCS\s*=\s*(.*)$", mk, re.M).group(1).split())
     assert listed == {os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip"))}
+
+
+def test_generated_attention_loop_is_reproducible_and_barrier_balanced():
+    """The hand-placed dK/dV main loop is a GENERATED inline-asm statement (nvit_amd/csrc/gen/gen_attn_dkv32_asm.py ->
+    attn_dkv32_asm.inc, committed).  (1) the committed file is what the generator writes; (2) interpreting its scalar control
+    flow for every wave role (computing wave / wave without keys) and tile counts incl. ragged and short last tiles, each
+    role executes the same number of s_barrier - a mismatch would hang the workgroup on the GPU - and the computing wave
+    issues the expected number of MFMAs."""
+    import importlib.util, subprocess, sys
+    csrc = os.path.join(ROOT, "nvit_amd", "csrc")
+    env = {k: v for k, v in os.environ.items() if k not in ("GEN_PROBE", "GEN_OPT")}
+    out = subprocess.run([sys.executable, os.path.join(csrc, "gen", "gen_attn_dkv32_asm.py")], capture_output=True, text=True,
+                         env=env, check=True).stdout
+    assert out == open(os.path.join(csrc, "attn_dkv32_asm.inc")).read(), "attn_dkv32_asm.inc is stale: make -C nvit_amd/csrc gen"
+    spec = importlib.util.spec_from_file_location("asm_barrier_sim", os.path.join(ROOT, "tools", "probes", "asm_barrier_sim.py"))
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    ins = sim.load(os.path.join(csrc, "attn_dkv32_asm.inc"))
+    for T in (16, 33, 49, 64, 65, 96, 128, 200, 784, 833):
+        nt = (T + 63) // 64
+        nvl = T - (nt - 1) * 64
+        res = {}
+        for act in (1, 0):
+            for w in range(4):
+                res[(act, w)] = sim.run(ins, {6: nt, 9: nvl, 10: act, 11: w * 1024, 8: 0, 7: 1536})
+        assert len({r["s_barrier"] for r in res.values()}) == 1, (T, {k: r["s_barrier"] for k, r in res.items()})
+        # per full tile 64 MFMAs; the last tile runs 72 (full) or 40 (short) counting the pre-step and the drain
+        assert res[(1, 0)]["mfma"] == (nt - 1) * 64 + (40 if nvl <= 32 else 72), (T, res[(1, 0)]["mfma"])
+        assert res[(0, 0)]["mfma"] == 0 and res[(1, 0)]["dma"] == 5 * nt
