@@ -20,9 +20,11 @@ usage: python3 gen_attn_dkv32_asm.py > ../attn_dkv32_asm.inc
 import os
 
 PROBE = set(filter(None, os.environ.get("GEN_PROBE", "").split(",")))
-# placement options (results stay exact).  Product = ring4,spreadtr,earlyrows: -1.6 % kernel cycles together against none of
-# them (profiles/r04_dkv_cycles_ring4_spread.log); GEN_OPT=none builds without; vsched (one transcendental per MFMA gap): +-0
-OPT = set(filter(None, (os.environ.get("GEN_OPT") or "ring4,spreadtr,earlyrows").split(","))) - {"none"}
+# placement options (results stay exact).  Product = ring4,spreadtr,earlyrows,prio: the first three -1.6 % kernel cycles
+# together against none of them (profiles/r04_dkv_cycles_ring4_spread.log), prio (s_setprio 1 for the tile loop: it
+# outranks a partner wave that is in its prologue / epilogue) another -1.8 % (profiles/r04_dkv_cycles_prio.log);
+# GEN_OPT=none builds without; vsched (one transcendental per MFMA gap): +-0
+OPT = set(filter(None, (os.environ.get("GEN_OPT") or "ring4,spreadtr,earlyrows,prio").split(","))) - {"none"}
 
 SLOT = 2 * 8192 + 512      # Q tile | dO tile | -lse[64] | -delta[64]   (= DKV_SLOT of attn_mfma.hip)
 RING4 = "ring4" in OPT     # 4-slot ring: the fetch of tile t+2 is spread over steps 0..2 of tile t (it may overwrite the slot of
@@ -523,6 +525,8 @@ def emit():
     e("s_waitcnt lgkmcnt(0)")
     for m in m1_atoms(0, 0):
         e(m)
+    if "prio" in OPT:
+        e("s_setprio 1")       # the tile loop outranks a partner wave that is in its prologue / epilogue
     e(f"s_add_u32 s{S_TMP}, s{S_T}, 1")
     e(f"s_cmp_lt_u32 s{S_TMP}, s{S_NT}")
     e("s_cbranch_scc0 .Llast_tile_%=")
@@ -586,6 +590,8 @@ def emit():
     for m in m2_atoms(1, 1):
         e(m)
     e(".Ldrained_%=:")
+    if "prio" in OPT:
+        e("s_setprio 0")
     stamp(3)
     e("s_nop 15")
     e("s_nop 15")
