@@ -1063,8 +1063,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm32_kernel(const bf16* 
 #pragma unroll
   for (int df = 0; df < 4; ++df)
     tro[df] = (unsigned)(swz_off(4 * lg + (l15 >> 2), 2 * df + ((l15 & 3) >> 1)) + ((l15 & 1) << 3));
-  const unsigned pack0 = a0 | (a1 << 16), pack1 = (unsigned)(lg * 16) | (tro[0] << 16), pack2 = tro[1] | (tro[2] << 16),
-                 pack3 = tro[3];
   const unsigned ring = lds_addr(&lds[0]);
   const unsigned dump = ring + (unsigned)wid * 16384u + (unsigned)lane * 16u;
   const unsigned long long s_q = uni64(qh + (size_t)bh * Tq * D);
@@ -1079,7 +1077,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_asm32_kernel(const bf16* 
                :
                : "s"(s_q), "s"(s_g), "s"(s_l), "s"(s_d), "s"(s_k), "s"(s_v), "s"(s_nt), "s"(s_ldg), "s"(s_ring), "s"(s_nvl),
                  "s"(s_act), "s"(s_wofs), "v"(voff_q0), "v"(voff_g0), "v"(rows_last), "v"((unsigned)chunk * 16u),
-                 "v"((unsigned)lane * 4u), "v"(kvoff[0]), "v"(kvoff[1]), "v"(pack0), "v"(pack1), "v"(pack2), "v"(pack3),
+                 "v"((unsigned)lane * 4u), "v"(kvoff[0]), "v"(kvoff[1]), "v"(a0), "v"(a1), "v"((unsigned)(lg * 16)), "v"(tro[0]),
+                 "v"(tro[1]), "v"(tro[2]), "v"(tro[3]),
                  "v"(dump)
                : NVIT_ATTN_DKV32_ASM_CLOBBERS);
   // lane-dependent values are formed afresh behind the loop: nothing per-lane has to live across it (16 registers are all the

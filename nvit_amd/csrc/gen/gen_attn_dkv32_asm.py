@@ -33,7 +33,8 @@ NSLOT = 4 if RING4 else 3
 NDMA = 6                   # DMA wave-instructions per wave per tile
 
 OP = dict(qbase=0, gbase=1, lbase=2, dbase=3, kbase=4, vbase=5, nt=6, ldg=7, ring=8, nvalid_last=9, active=10, wofs=11,
-          voff_q0=12, voff_g0=13, rows_last=14, chunk16=15, lane4=16, kvoff0=17, lds_pack0=19, dump=23)
+          voff_q0=12, voff_g0=13, rows_last=14, chunk16=15, lane4=16, kvoff0=17, lds_a0=19, lds_a1=20, lds_rn=21, lds_tr0=22,
+          dump=26)
 
 S_Q, S_G, S_L, S_D = 40, 42, 44, 46
 S_NT, S_LDG, S_RING, S_NVL = 48, 49, 50, 51
@@ -44,7 +45,7 @@ S_P32, S_T64, S_WOFS, S_RINGEND = 60, 61, 62, 63
 S_SAVE = 64
 S_FLAGS, S_DW, S_M0, S_SLOTT = 66, 67, 68, 69     # S_SLOTT: LDS base of the tile whose transposed fragments are being read
 
-# per-lane operands (voff_q0, voff_g0, rows_last, chunk16, lane4, kvoff, packed LDS offsets, dump) are read straight from the
+# per-lane operands (voff_q0, voff_g0, rows_last, chunk16, lane4, kvoff, the seven LDS lane offsets, dump) are read straight from the
 # statement's input registers: a wave has 256 registers, 96 of them in the accumulation half, 16 left to the compiler
 V_RA0, V_RA1, V_RN, V_RT = 16, 17, 18, 19      # absolute LDS addresses: rows (may already point at the next tile) / transposed
 V_TMP, V_TMP2 = 23, 24
@@ -270,21 +271,13 @@ def next_slot(dst, src):
 
 
 def set_row_addresses():
-    p0, p1 = OP['lds_pack0'], OP['lds_pack0'] + 1
-    e(f"v_and_b32_e32 v{V_TMP}, 0xffff, %{p0}")
-    e(f"v_add_u32_e32 v{V_RA0}, s{S_SLOTC}, v{V_TMP}")
-    e(f"v_lshrrev_b32_e32 v{V_TMP}, 16, %{p0}")
-    e(f"v_add_u32_e32 v{V_RA1}, s{S_SLOTC}, v{V_TMP}")
-    e(f"v_and_b32_e32 v{V_TMP}, 0xffff, %{p1}")
-    e(f"v_add_u32_e32 v{V_RN}, s{S_SLOTC}, v{V_TMP}")
+    e(f"v_add_u32_e32 v{V_RA0}, s{S_SLOTC}, %{OP['lds_a0']}")
+    e(f"v_add_u32_e32 v{V_RA1}, s{S_SLOTC}, %{OP['lds_a1']}")
+    e(f"v_add_u32_e32 v{V_RN}, s{S_SLOTC}, %{OP['lds_rn']}")
 
 
 def tr_address_atoms():
-    p1, p2, p3 = OP['lds_pack0'] + 1, OP['lds_pack0'] + 2, OP['lds_pack0'] + 3
-    return [f"v_lshrrev_b32_e32 v{V_TMP}, 16, %{p1}", f"v_add_u32_e32 v{V_RT}, s{S_SLOTT}, v{V_TMP}",
-            f"v_and_b32_e32 v{V_TMP}, 0xffff, %{p2}", f"v_add_u32_e32 v{V_RT + 1}, s{S_SLOTT}, v{V_TMP}",
-            f"v_lshrrev_b32_e32 v{V_TMP}, 16, %{p2}", f"v_add_u32_e32 v{V_RT + 2}, s{S_SLOTT}, v{V_TMP}",
-            f"v_add_u32_e32 v{V_RT + 3}, s{S_SLOTT}, %{p3}"]
+    return [f"v_add_u32_e32 v{V_RT + i}, s{S_SLOTT}, %{OP['lds_tr0'] + i}" for i in range(4)]
 
 
 def place(mf, va, after=None, dma=(), v_from=0, v_keep=3, dma_keep=0):
@@ -378,11 +371,12 @@ def step(j, do_m1=True, do_m2=True, row_next=None, tr_this=None, dma=(), pre_row
         # the transposed fragments of d-block df are free once M2's MFMA pair df has issued: request their successors there
         # instead of all 16 behind the last pair (same order, so the counted waits of the next step hold)
         rd = tr_reads(tr_this)
-        after[0] = after.get(0, []) + tr_address_atoms()
+        if tr_this == 0:       # (both halves of a tile read the same slot: the addresses of step 0 serve step 2)
+            after[0] = after.get(0, []) + tr_address_atoms()
         for df in range(4):
             after[2 * df + 1] = after.get(2 * df + 1, []) + rd[4 * df:4 * df + 4]
     elif tr_this is not None and not nolds:
-        blk = tr_address_atoms() + tr_reads(tr_this)
+        blk = (tr_address_atoms() if tr_this == 0 else []) + tr_reads(tr_this)
         if k2 >= 0:
             after[k2] = after.get(k2, []) + blk
         else:
@@ -616,7 +610,7 @@ def emit():
             e(f"v_mov_b32_e32 v{V_ROW + i}, s{r}")
         e(f"v_mov_b32_e32 v{V_ROW + 15}, 0")
         for i in range(3):
-            e(f"global_store_dwordx4 v{V_ROW + 15}, {vr(V_ROW + 4 * i)}, %24 offset:{16 * i}")
+            e(f"global_store_dwordx4 v{V_ROW + 15}, {vr(V_ROW + 4 * i)}, %{OP['dump'] + 1} offset:{16 * i}")
         e("s_waitcnt vmcnt(0)")
         e(f"s_mov_b64 exec, s[{S_SAVE}:{S_SAVE + 1}]")
     e("s_branch .Lend_%=")
