@@ -52,6 +52,8 @@ const char* nvit_last_error(void);
 #define NVIT_KID_OPTIM 13           /* nvit_grad_sqnorm + nvit_adamw_renorm (NVIT_KID_RENORM = stand-alone nvit_renorm_weights) */
 #define NVIT_KID_COUNT 14
 void nvit_prof_enable(int on);
+/* time only the families whose bit is set (bit k = family k of nvit_prof_name); nvit_prof_enable(1) = all, (0) = none */
+void nvit_prof_select(unsigned mask);
 /* Synchronises the recorded events and returns, per kernel family, total milliseconds,
  * algorithmic FLOPs, algorithmic bytes and launch count since the last collect. Host arrays
  * of NVIT_KID_COUNT entries. */

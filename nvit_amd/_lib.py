@@ -25,6 +25,7 @@ SIGNATURES = {
     "nvit_version": [],
     "nvit_last_error": [],
     "nvit_prof_enable": [_i],
+    "nvit_prof_select": [C.c_uint],
     "nvit_prof_collect": [_vp, _vp, _vp, _vp],
     "nvit_prof_name": [_i],
     "nvit_renorm_weights": [_vp, _i, _i, _vp],
@@ -100,7 +101,7 @@ SIGNATURES = {
     "nvit_xgmi_errword_free": [_vp],
     "nvit_set_attn_dkv_asm": [_i],
 }
-_RESTYPES = {"nvit_last_error": C.c_char_p, "nvit_prof_name": C.c_char_p, "nvit_prof_enable": None,
+_RESTYPES = {"nvit_last_error": C.c_char_p, "nvit_prof_name": C.c_char_p, "nvit_prof_enable": None, "nvit_prof_select": None,
              "nvit_xgmi_chunk": C.c_int64, "nvit_xgmi_flag_bytes": C.c_int64}
 
 _lib = None

@@ -30,7 +30,7 @@ struct Rec {
 std::mutex g_mu;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
-volatile int g_on = 0;
+volatile unsigned g_on = 0;   // bit k: launches of kernel family k are timed
 thread_local Rec g_open[NVIT_KID_COUNT];
 thread_local bool g_has_open[NVIT_KID_COUNT];
 
@@ -48,7 +48,7 @@ hipEvent_t get_event() {
 }  // namespace
 
 void nvit_prof_begin(int kid, double flops, double bytes, hipStream_t s) {
-  if (!g_on) return;
+  if (!((g_on >> kid) & 1u)) return;
   Rec r;
   r.kid = kid;
   r.a = get_event();
@@ -69,7 +69,8 @@ void nvit_prof_end(int kid, hipStream_t s) {
   g_recs.push_back(r);
 }
 
-extern "C" void nvit_prof_enable(int on) { g_on = on; }
+extern "C" void nvit_prof_enable(int on) { g_on = on ? ~0u : 0u; }
+extern "C" void nvit_prof_select(unsigned mask) { g_on = mask; }
 
 extern "C" int nvit_prof_collect(double* ms, double* flops, double* bytes, int64_t* launches) {
   std::vector<Rec> recs;

@@ -676,6 +676,14 @@ def prof_enable(on: bool) -> None:
     _lib.load().nvit_prof_enable(int(on))
 
 
+def prof_select(*families: str) -> None:
+    """time only the launches of the named kernel families (names: _lib.KID_NAMES)"""
+    mask = 0
+    for f in families:
+        mask |= 1 << _lib.KID_NAMES.index(f)
+    _lib.load().nvit_prof_select(mask)
+
+
 def prof_collect():
     n = len(_lib.KID_NAMES)
     ms = (C.c_double * n)()
