@@ -68,6 +68,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_off) {
       : "memory");
 }
 
+// The same with the source split into a wave-uniform 64-bit base (scalar registers) and a 32-bit per-lane byte offset: the
+// per-stage part of the address (which k-slab, which tile) is scalar arithmetic, not two vector adds per piece, and a
+// lane's address costs one register instead of two.
+__device__ __forceinline__ void glds16s(unsigned long long sbase, unsigned voff, unsigned lds_off) {
+  unsigned keep;
+  const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_off);
+  const unsigned long long sb = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sbase) |
+                                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sbase >> 32)) << 32);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sb), "s"(m)
+      : "memory");
+}
+
 // 16-byte non-temporal global store.  GEMM outputs are written once and read by a LATER kernel; storing them with
 // the nt policy keeps them from evicting the A/B operand tiles that the next tiles of THIS kernel re-read from L2
 // (measured on 256x256 tiles: -7 % (bf16 out) / -10 % (fp32 out) per tile at K = 1536, -1..3 % at K = 768).

@@ -107,8 +107,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
   };
 
   // ---- load cursor: LDS-DMA, one wave-instruction = 8 rows of 128 B; wave w owns groups 8*i + w
-  const char* ap[Cfg::A_DMA];
-  const char* bp[Cfg::B_DMA];
+  // (a tile's rows as 32-bit lane offsets from the tile's first row; the tile / k-slab part of the address is scalar)
+  unsigned aoff[Cfg::A_DMA], boff[Cfg::B_DMA];
+  unsigned long long abase = 0, bbase = 0;
   int l_it = 0, l_k = 0, l_slot = 0;
   // dynamic scheduling state (all wave-uniform except `ticket`, which only thread 0 uses)
   bool l_valid = true;      // the load cursor still has a tile
@@ -138,23 +139,25 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
     for (int i = 0; i < Cfg::A_DMA; ++i) {
       int ra = m0 + (i * 8 + wid) * 8 + srow;
       ra = ra < g.M ? ra : g.M - 1;
-      ap[i] = g.A + ((size_t)ra * g.lda + (size_t)gc * EPC) * sizeof(T);
+      aoff[i] = (unsigned)(((size_t)(ra - m0) * g.lda + (size_t)gc * EPC) * sizeof(T));
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_DMA; ++i) {
       int rb = n0 + (i * 8 + wid) * 8 + srow;
       rb = rb < g.N ? rb : g.N - 1;
-      bp[i] = g.B + ((size_t)rb * g.ldb + (size_t)gc * EPC) * sizeof(T);
+      boff[i] = (unsigned)(((size_t)(rb - n0) * g.ldb + (size_t)gc * EPC) * sizeof(T));
     }
+    abase = (unsigned long long)(uintptr_t)g.A + (unsigned long long)((size_t)m0 * g.lda * sizeof(T));
+    bbase = (unsigned long long)(uintptr_t)g.B + (unsigned long long)((size_t)n0 * g.ldb * sizeof(T));
   };
   auto issue_stage = [&]() {
     const unsigned bo = lds_base + wave_off + (unsigned)l_slot * SLOT_BYTES;
     const size_t ko = (size_t)l_k * ROWB;
     {
 #pragma unroll
-      for (int i = 0; i < Cfg::A_DMA; ++i) glds16(ap[i] + ko, bo + i * 8192);
+      for (int i = 0; i < Cfg::A_DMA; ++i) glds16s(abase + ko, aoff[i], bo + i * 8192);
 #pragma unroll
-      for (int i = 0; i < Cfg::B_DMA; ++i) glds16(bp[i] + ko, bo + A_BYTES + i * 8192);
+      for (int i = 0; i < Cfg::B_DMA; ++i) glds16s(bbase + ko, boff[i], bo + A_BYTES + i * 8192);
     }
     l_slot = l_slot == NSLOT - 1 ? 0 : l_slot + 1;
     if (++l_k == nt) {

@@ -98,10 +98,22 @@ __global__ __launch_bounds__(512) NVIT_TN_VGPR_ATTR void gemm_tn_persistent_kern
     return rows > 0 ? (rows + RB - 1) / RB : 0;
   };
 
-  // ---- load cursor
-  const char* abase[ODMA];
-  const char* bbase[ODMA];
+  // ---- load cursor: a lane's rows / chunks never change (32-bit offsets, formed once); the item and the row slab are the
+  // scalar part of the address
+  unsigned aoff[ODMA], boff[ODMA];
   int srow[ODMA];
+#pragma unroll
+  for (int i = 0; i < ODMA; ++i) {
+    srow[i] = (i * 8 + wid) * RPI + lrow;
+    int ch;
+    if constexpr (sizeof(T) == 2)
+      ch = lslot ^ tnp_swz(srow[i]);
+    else
+      ch = lslot;
+    aoff[i] = (unsigned)(((size_t)srow[i] * g.lda + (size_t)ch * EPC) * sizeof(T));
+    boff[i] = (unsigned)(((size_t)srow[i] * g.ldb + (size_t)ch * EPC) * sizeof(T));
+  }
+  unsigned long long a_item = 0, b_item = 0;   // first row of the item's slab, its column block
   int l_it = 0, l_t = 0, l_nt = 0, l_mbeg = 0, l_mend = 0, l_slot = 0;
   size_t astep = (size_t)RB * g.lda * sizeof(T), bstep = (size_t)RB * g.ldb * sizeof(T);
   auto set_load_item = [&](int it) {
@@ -109,17 +121,8 @@ __global__ __launch_bounds__(512) NVIT_TN_VGPR_ATTR void gemm_tn_persistent_kern
     item_of(it, n0, k0, l_mbeg, l_mend, split);
     const int rows = l_mend - l_mbeg;
     l_nt = rows > 0 ? (rows + RB - 1) / RB : 0;
-#pragma unroll
-    for (int i = 0; i < ODMA; ++i) {
-      srow[i] = (i * 8 + wid) * RPI + lrow;
-      int ch;
-      if constexpr (sizeof(T) == 2)
-        ch = lslot ^ tnp_swz(srow[i]);
-      else
-        ch = lslot;
-      abase[i] = g.A + ((size_t)(l_mbeg + srow[i]) * g.lda + n0 + ch * EPC) * sizeof(T);
-      bbase[i] = g.B + ((size_t)(l_mbeg + srow[i]) * g.ldb + k0 + ch * EPC) * sizeof(T);
-    }
+    a_item = (unsigned long long)(uintptr_t)g.A + (unsigned long long)(((size_t)l_mbeg * g.lda + n0) * sizeof(T));
+    b_item = (unsigned long long)(uintptr_t)g.B + (unsigned long long)(((size_t)l_mbeg * g.ldb + k0) * sizeof(T));
   };
   auto advance_to_nonempty = [&]() {
     while (l_it < my_items && l_nt == 0) {
@@ -129,13 +132,23 @@ __global__ __launch_bounds__(512) NVIT_TN_VGPR_ATTR void gemm_tn_persistent_kern
   };
   auto issue_stage = [&]() {
     const unsigned bo = lds_base + wave_off + (unsigned)l_slot * TSLOT_BYTES;
+    const unsigned long long sa = a_item + (unsigned long long)((size_t)l_t * astep);
+    const unsigned long long sb = b_item + (unsigned long long)((size_t)l_t * bstep);
+    if (l_mbeg + (l_t + 1) * RB <= l_mend) {   // (wave-uniform) a full slab: scalar base + lane offset
 #pragma unroll
-    for (int i = 0; i < ODMA; ++i) {
-      const bool mok = (l_mbeg + l_t * RB + srow[i]) < l_mend;
-      const char* pa = mok ? abase[i] + (size_t)l_t * astep : zsrc;
-      const char* pb = mok ? bbase[i] + (size_t)l_t * bstep : zsrc;
-      glds16(pa, bo + i * 8192);
-      glds16(pb, bo + OP_BYTES + i * 8192);
+      for (int i = 0; i < ODMA; ++i) {
+        glds16s(sa, aoff[i], bo + i * 8192);
+        glds16s(sb, boff[i], bo + OP_BYTES + i * 8192);
+      }
+    } else {                                   // the item's ragged last slab: rows past its end come from the zero page
+#pragma unroll
+      for (int i = 0; i < ODMA; ++i) {
+        const bool mok = (l_mbeg + l_t * RB + srow[i]) < l_mend;
+        const char* pa = mok ? reinterpret_cast<const char*>((uintptr_t)sa) + aoff[i] : zsrc;
+        const char* pb = mok ? reinterpret_cast<const char*>((uintptr_t)sb) + boff[i] : zsrc;
+        glds16(pa, bo + i * 8192);
+        glds16(pb, bo + OP_BYTES + i * 8192);
+      }
     }
     l_slot = l_slot == NSLOT - 1 ? 0 : l_slot + 1;
     if (++l_t == l_nt) {
