@@ -83,6 +83,40 @@ __device__ __forceinline__ void glds16s(unsigned long long sbase, unsigned voff,
       : "memory");
 }
 
+// N (2 or 4) such pieces of one operand in ONE statement - LDS destinations lds_off + i * 8 KiB, lane offsets voff[i] from
+// the same scalar base: M0 is saved and restored once per operand instead of once per piece, and the destinations are
+// formed by scalar adds into M0 itself (the per-piece form costs ~8 scalar instructions per piece; an in-order wave
+// pays for every one of them beside its MFMAs).
+template <int N>
+__device__ __forceinline__ void glds16s_n(unsigned long long sbase, const unsigned (&voff)[N], unsigned lds_off) {
+  static_assert(N == 2 || N == 4, "2 or 4 pieces");
+  unsigned keep;
+  const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_off);
+  const unsigned long long sb = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sbase) |
+                                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sbase >> 32)) << 32);
+  if constexpr (N == 4) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+        "s_add_u32 m0, %6, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+        "s_add_u32 m0, %6, 0x4000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+        "s_add_u32 m0, %6, 0x6000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sb), "s"(m)
+        : "memory", "scc");
+  } else {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+        "s_add_u32 m0, %4, 0x2000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff[0]), "v"(voff[1]), "s"(sb), "s"(m)
+        : "memory", "scc");
+  }
+}
+
 // 16-byte non-temporal global store.  GEMM outputs are written once and read by a LATER kernel; storing them with
 // the nt policy keeps them from evicting the A/B operand tiles that the next tiles of THIS kernel re-read from L2
 // (measured on 256x256 tiles: -7 % (bf16 out) / -10 % (fp32 out) per tile at K = 1536, -1..3 % at K = 768).

@@ -154,10 +154,8 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
     const unsigned bo = lds_base + wave_off + (unsigned)l_slot * SLOT_BYTES;
     const size_t ko = (size_t)l_k * ROWB;
     {
-#pragma unroll
-      for (int i = 0; i < Cfg::A_DMA; ++i) glds16s(abase + ko, aoff[i], bo + i * 8192);
-#pragma unroll
-      for (int i = 0; i < Cfg::B_DMA; ++i) glds16s(bbase + ko, boff[i], bo + A_BYTES + i * 8192);
+      glds16s_n<Cfg::A_DMA>(abase + ko, aoff, bo);
+      glds16s_n<Cfg::B_DMA>(bbase + ko, boff, bo + A_BYTES);
     }
     l_slot = l_slot == NSLOT - 1 ? 0 : l_slot + 1;
     if (++l_k == nt) {

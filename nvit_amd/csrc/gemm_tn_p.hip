@@ -135,11 +135,8 @@ __global__ __launch_bounds__(512) NVIT_TN_VGPR_ATTR void gemm_tn_persistent_kern
     const unsigned long long sa = a_item + (unsigned long long)((size_t)l_t * astep);
     const unsigned long long sb = b_item + (unsigned long long)((size_t)l_t * bstep);
     if (l_mbeg + (l_t + 1) * RB <= l_mend) {   // (wave-uniform) a full slab: scalar base + lane offset
-#pragma unroll
-      for (int i = 0; i < ODMA; ++i) {
-        glds16s(sa, aoff[i], bo + i * 8192);
-        glds16s(sb, boff[i], bo + OP_BYTES + i * 8192);
-      }
+      glds16s_n<ODMA>(sa, aoff, bo);
+      glds16s_n<ODMA>(sb, boff, bo + OP_BYTES);
     } else {                                   // the item's ragged last slab: rows past its end come from the zero page
 #pragma unroll
       for (int i = 0; i < ODMA; ++i) {
