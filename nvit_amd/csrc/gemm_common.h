@@ -225,8 +225,15 @@ __device__ __forceinline__ void nt_store_tile_staged(const NtArgs& g, f32x4 (&ac
 #pragma unroll
   for (int i = 0; i < FMR; ++i) {
     const int mfrag = m_base + i * 16 + l15;
-    const float* radd =
-        g.rowadd ? g.rowadd + (size_t)((mfrag < g.M ? mfrag : g.M - 1) % g.rowadd_period) * g.N : nullptr;
+    // (the row-periodic addend is a rare option - the exact-f32 patch embedding: the branch and the empty statement keep
+    //  its per-lane modulo out of the persistent kernel's stage loop, where the compiler otherwise computes it
+    //  speculatively every stage, ~17 VALU beside the MFMAs)
+    const float* radd = nullptr;
+    if (g.rowadd) {
+      int rrow = (mfrag < g.M ? mfrag : g.M - 1) % g.rowadd_period;
+      asm volatile("" : "+v"(rrow));
+      radd = g.rowadd + (size_t)rrow * g.N;
+    }
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
       const int pass = i * PASSES + p;

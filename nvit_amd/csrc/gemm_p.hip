@@ -108,7 +108,12 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
 
   // ---- load cursor: LDS-DMA, one wave-instruction = 8 rows of 128 B; wave w owns groups 8*i + w
   // (a tile's rows as 32-bit lane offsets from the tile's first row; the tile / k-slab part of the address is scalar)
-  unsigned aoff[Cfg::A_DMA], boff[Cfg::B_DMA];
+  // Only waves 0-3 issue LDS-DMA - their own row groups and those of the wave that shares their SIMD (wave + 4): an LDS-DMA
+  // instruction stalls the issuing wave for ~50 cycles and a wave cannot multiply meanwhile, but its SIMD partner can:
+  // the loader's DMA block runs beside the partner's first MFMAs instead of both waves issuing DMA, then both
+  // contending for the matrix pipe.
+  const bool loader = wid < 4;
+  unsigned aoff[2][Cfg::A_DMA], boff[2][Cfg::B_DMA];
   unsigned long long abase = 0, bbase = 0;
   int l_it = 0, l_k = 0, l_slot = 0;
   // dynamic scheduling state (all wave-uniform except `ticket`, which only thread 0 uses)
@@ -135,17 +140,23 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
   auto set_load_tile = [&](int pid) {
     int m0, n0;
     tile_of(pid, m0, n0);
+    if (loader) {
 #pragma unroll
-    for (int i = 0; i < Cfg::A_DMA; ++i) {
-      int ra = m0 + (i * 8 + wid) * 8 + srow;
-      ra = ra < g.M ? ra : g.M - 1;
-      aoff[i] = (unsigned)(((size_t)(ra - m0) * g.lda + (size_t)gc * EPC) * sizeof(T));
-    }
+      for (int h = 0; h < 2; ++h) {
+        const int w = wid + 4 * h;
 #pragma unroll
-    for (int i = 0; i < Cfg::B_DMA; ++i) {
-      int rb = n0 + (i * 8 + wid) * 8 + srow;
-      rb = rb < g.N ? rb : g.N - 1;
-      boff[i] = (unsigned)(((size_t)(rb - n0) * g.ldb + (size_t)gc * EPC) * sizeof(T));
+        for (int i = 0; i < Cfg::A_DMA; ++i) {
+          int ra = m0 + (i * 8 + w) * 8 + srow;
+          ra = ra < g.M ? ra : g.M - 1;
+          aoff[h][i] = (unsigned)(((size_t)(ra - m0) * g.lda + (size_t)gc * EPC) * sizeof(T));
+        }
+#pragma unroll
+        for (int i = 0; i < Cfg::B_DMA; ++i) {
+          int rb = n0 + (i * 8 + w) * 8 + srow;
+          rb = rb < g.N ? rb : g.N - 1;
+          boff[h][i] = (unsigned)(((size_t)(rb - n0) * g.ldb + (size_t)gc * EPC) * sizeof(T));
+        }
+      }
     }
     abase = (unsigned long long)(uintptr_t)g.A + (unsigned long long)((size_t)m0 * g.lda * sizeof(T));
     bbase = (unsigned long long)(uintptr_t)g.B + (unsigned long long)((size_t)n0 * g.ldb * sizeof(T));
@@ -154,8 +165,12 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
     const unsigned bo = lds_base + wave_off + (unsigned)l_slot * SLOT_BYTES;
     const size_t ko = (size_t)l_k * ROWB;
     {
-      glds16s_n<Cfg::A_DMA>(abase + ko, aoff, bo);
-      glds16s_n<Cfg::B_DMA>(bbase + ko, boff, bo + A_BYTES);
+      if (loader) {
+        glds16s_n<Cfg::A_DMA>(abase + ko, aoff[0], bo);
+        glds16s_n<Cfg::A_DMA>(abase + ko, aoff[1], bo + 4096);
+        glds16s_n<Cfg::B_DMA>(bbase + ko, boff[0], bo + A_BYTES);
+        glds16s_n<Cfg::B_DMA>(bbase + ko, boff[1], bo + A_BYTES + 4096);
+      }
     }
     l_slot = l_slot == NSLOT - 1 ? 0 : l_slot + 1;
     if (++l_k == nt) {
@@ -209,8 +224,9 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
   issue_stage();
   const bool two_ahead = NSLOT > 2 && (DYN || total_stages > 1);   // DYN requires nt >= NSLOT + 4 (host check)
   if (two_ahead) issue_stage();
-  if (two_ahead)
-    wait_vmcnt<(NSLOT > 2 ? DPS : 0)>();
+  // (counted waits: a loader wave has 2 * DPS DMA instructions per stage in flight, the other waves none)
+  if (two_ahead && loader)
+    wait_vmcnt<(NSLOT > 2 ? 2 * DPS : 0)>();
   else
     wait_vmcnt<0>();
   __syncthreads();
@@ -319,12 +335,16 @@ __global__ __launch_bounds__(512) void gemm_nt_persistent_kernel(NtArgs g, int t
     // for what is older than them, so the write-back drains under the next tile's first stage instead of
     // stalling the whole workgroup on HBM write acknowledgements.
     if (stored) {
-      if (full_tile && issued_now)
-        wait_vmcnt<(NSLOT - 2) * DPS + NST>();
-      else
+      if (full_tile && issued_now) {
+        if (loader)
+          wait_vmcnt<(NSLOT - 2) * 2 * DPS + NST>();
+        else
+          wait_vmcnt<NST>();
+      } else {
         wait_vmcnt<0>();
-    } else if (NSLOT > 2 && issued_now) {
-      wait_vmcnt<(NSLOT > 2 ? (NSLOT - 2) * DPS : 0)>();
+      }
+    } else if (NSLOT > 2 && issued_now && loader) {
+      wait_vmcnt<(NSLOT > 2 ? (NSLOT - 2) * 2 * DPS : 0)>();
     } else {
       wait_vmcnt<0>();
     }
