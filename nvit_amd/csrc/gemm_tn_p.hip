@@ -100,19 +100,23 @@ __global__ __launch_bounds__(512) NVIT_TN_VGPR_ATTR void gemm_tn_persistent_kern
 
   // ---- load cursor: a lane's rows / chunks never change (32-bit offsets, formed once); the item and the row slab are the
   // scalar part of the address
-  unsigned aoff[ODMA], boff[ODMA];
-  int srow[ODMA];
+  // Only waves 0-3 issue LDS-DMA, for their own row groups and those of their SIMD partner (wave + 4): see gemm_p.hip.
+  const bool loader = wid < 4;
+  unsigned aoff[2][ODMA], boff[2][ODMA];
+  int srow[2][ODMA];
 #pragma unroll
-  for (int i = 0; i < ODMA; ++i) {
-    srow[i] = (i * 8 + wid) * RPI + lrow;
-    int ch;
-    if constexpr (sizeof(T) == 2)
-      ch = lslot ^ tnp_swz(srow[i]);
-    else
-      ch = lslot;
-    aoff[i] = (unsigned)(((size_t)srow[i] * g.lda + (size_t)ch * EPC) * sizeof(T));
-    boff[i] = (unsigned)(((size_t)srow[i] * g.ldb + (size_t)ch * EPC) * sizeof(T));
-  }
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < ODMA; ++i) {
+      srow[h][i] = (i * 8 + (wid & 3) + 4 * h) * RPI + lrow;
+      int ch;
+      if constexpr (sizeof(T) == 2)
+        ch = lslot ^ tnp_swz(srow[h][i]);
+      else
+        ch = lslot;
+      aoff[h][i] = (unsigned)(((size_t)srow[h][i] * g.lda + (size_t)ch * EPC) * sizeof(T));
+      boff[h][i] = (unsigned)(((size_t)srow[h][i] * g.ldb + (size_t)ch * EPC) * sizeof(T));
+    }
   unsigned long long a_item = 0, b_item = 0;   // first row of the item's slab, its column block
   int l_it = 0, l_t = 0, l_nt = 0, l_mbeg = 0, l_mend = 0, l_slot = 0;
   size_t astep = (size_t)RB * g.lda * sizeof(T), bstep = (size_t)RB * g.ldb * sizeof(T);
@@ -131,20 +135,27 @@ __global__ __launch_bounds__(512) NVIT_TN_VGPR_ATTR void gemm_tn_persistent_kern
     }
   };
   auto issue_stage = [&]() {
-    const unsigned bo = lds_base + wave_off + (unsigned)l_slot * TSLOT_BYTES;
+    const unsigned bo0 = lds_base + (unsigned)((wid & 3) * 1024) + (unsigned)l_slot * TSLOT_BYTES;
     const unsigned long long sa = a_item + (unsigned long long)((size_t)l_t * astep);
     const unsigned long long sb = b_item + (unsigned long long)((size_t)l_t * bstep);
-    if (l_mbeg + (l_t + 1) * RB <= l_mend) {   // (wave-uniform) a full slab: scalar base + lane offset
-      glds16s_n<ODMA>(sa, aoff, bo);
-      glds16s_n<ODMA>(sb, boff, bo + OP_BYTES);
-    } else {                                   // the item's ragged last slab: rows past its end come from the zero page
+    if (loader) {
+      if (l_mbeg + (l_t + 1) * RB <= l_mend) {   // (wave-uniform) a full slab: scalar base + lane offset
 #pragma unroll
-      for (int i = 0; i < ODMA; ++i) {
-        const bool mok = (l_mbeg + l_t * RB + srow[i]) < l_mend;
-        const char* pa = mok ? reinterpret_cast<const char*>((uintptr_t)sa) + aoff[i] : zsrc;
-        const char* pb = mok ? reinterpret_cast<const char*>((uintptr_t)sb) + boff[i] : zsrc;
-        glds16(pa, bo + i * 8192);
-        glds16(pb, bo + OP_BYTES + i * 8192);
+        for (int h = 0; h < 2; ++h) {
+          glds16s_n<ODMA>(sa, aoff[h], bo0 + h * 4096);
+          glds16s_n<ODMA>(sb, boff[h], bo0 + h * 4096 + OP_BYTES);
+        }
+      } else {                                   // the item's ragged last slab: rows past its end come from the zero page
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < ODMA; ++i) {
+            const bool mok = (l_mbeg + l_t * RB + srow[h][i]) < l_mend;
+            const char* pa = mok ? reinterpret_cast<const char*>((uintptr_t)sa) + aoff[h][i] : zsrc;
+            const char* pb = mok ? reinterpret_cast<const char*>((uintptr_t)sb) + boff[h][i] : zsrc;
+            glds16(pa, bo0 + h * 4096 + i * 8192);
+            glds16(pb, bo0 + h * 4096 + OP_BYTES + i * 8192);
+          }
       }
     }
     l_slot = l_slot == NSLOT - 1 ? 0 : l_slot + 1;
@@ -199,10 +210,11 @@ __global__ __launch_bounds__(512) NVIT_TN_VGPR_ATTR void gemm_tn_persistent_kern
   // prologue: NSLOT-1 stages in flight, stage 0 landed
   int issued = 0;
   for (; issued < NSLOT - 1 && issued < total_stages; ++issued) issue_stage();
-  if (issued >= 3)
+  // (a loader wave has 2 * DPS DMA instructions per stage in flight, the other waves none)
+  if (issued >= 3 && loader)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DPS) : "memory");
+  else if (issued == 2 && loader)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPS) : "memory");
-  else if (issued == 2)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS) : "memory");
   else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -306,12 +318,12 @@ __global__ __launch_bounds__(512) NVIT_TN_VGPR_ATTR void gemm_tn_persistent_kern
     // retire DMA(s+1); the stages issued after it stay in flight.  (After an item's slab stores - younger than every
     // DMA in the queue - drain everything: once per item.)
     const int ahead = total_stages - 1 - (s + 1);   // stages issued beyond s+1 that exist
-    if (stored || NSLOT == 2 || ahead <= 0)
+    if (stored || NSLOT == 2 || ahead <= 0 || !loader)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if (ahead == 1)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DPS) : "memory");
-    else
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * DPS) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DPS) : "memory");
     __syncthreads();
     slot = slot == NSLOT - 1 ? 0 : slot + 1;
   }
