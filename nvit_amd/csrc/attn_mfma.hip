@@ -119,11 +119,26 @@ __device__ __forceinline__ void glds16s(const void* sbase, unsigned voff, unsign
       : "v"(voff), "s"(sb), "s"(m)
       : "memory");
 }
+// The two pieces a wave contributes to a tile (LDS destinations 4 KiB apart) in one statement: one M0 save / restore.
+__device__ __forceinline__ void glds16s_pair(const void* sbase, unsigned voff0, unsigned voff1, unsigned lds_off) {
+  unsigned keep;
+  const unsigned m = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_off);
+  const unsigned long long ub = (unsigned long long)(uintptr_t)sbase;
+  const unsigned long long sb = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ub) |
+                                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ub >> 32)) << 32);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+      "s_add_u32 m0, %4, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff0), "v"(voff1), "s"(sb), "s"(m)
+      : "memory", "scc");
+}
 // DMA one 64-row tile of `src` (row stride ld_bytes, rows clamped to nrows-1) to LDS byte offset tile_off;
 // 4 waves x 2 wave-instructions.  TILE_DMA = instructions per wave per tile.  `src`, row_base and nrows are wave
 // uniform; voff[i] = tile_voff(i, ...) are the lane's offsets inside a full tile, computed once per kernel.
 constexpr int TILE_DMA = 2;
-constexpr int DMA_REP = 1;
 __device__ __forceinline__ unsigned tile_voff(int i, unsigned ld_bytes, int lane, int wid) {
   const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
   return (unsigned)((i * 4 + wid) * 8 + r8) * ld_bytes + (unsigned)chunk * 16u;
@@ -132,10 +147,8 @@ __device__ __forceinline__ void tile_dma(const bf16* src, unsigned ld_bytes, int
                                          int lane, int wid, const unsigned (&voff)[TILE_DMA]) {
   const char* sb = reinterpret_cast<const char*>(src) + (size_t)row_base * ld_bytes;
   if (row_base + TKV <= nrows) {
-#pragma unroll
-    for (int rep = 0; rep < DMA_REP; ++rep)
-#pragma unroll
-    for (int i = 0; i < TILE_DMA; ++i) glds16s(sb, voff[i], tile_off + (i * 4 + wid) * 1024);
+    static_assert(TILE_DMA == 2, "glds16s_pair issues the tile's two pieces");
+    glds16s_pair(sb, voff[0], voff[1], tile_off + wid * 1024);
   } else {   // ragged last tile: rows past the end re-read the last valid row (finite values, masked by the consumer)
     const int r8 = lane >> 3, chunk = (lane & 7) ^ r8;
 #pragma unroll
@@ -143,8 +156,6 @@ __device__ __forceinline__ void tile_dma(const bf16* src, unsigned ld_bytes, int
       const int grp = i * 4 + wid;
       int row = grp * 8 + r8;
       row = row_base + row < nrows ? row : nrows - 1 - row_base;
-#pragma unroll
-      for (int rep = 0; rep < DMA_REP; ++rep)
       glds16s(sb, (unsigned)row * ld_bytes + (unsigned)chunk * 16u, tile_off + grp * 1024);
     }
   }
@@ -391,7 +402,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_mfma_kernel(const bf16* __res
           }
     }
     if (t + 2 < nt)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DMA_REP) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -701,7 +712,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_mfma_kernel(const bf16* __
           }
     }
     if (t + 2 < nt)
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * DMA_REP) : "memory");
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4) : "memory");
     else
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -751,7 +762,7 @@ __device__ __forceinline__ void glds4a(const void* gsrc, unsigned lds_off) {
 // -delta enters as the initial accumulator of the dP product, the softmax scale is applied once to the dK accumulators,
 // and P / dS are packed to bf16 as soon as a 16-query fragment is done, so only packed halves stay live.
 constexpr int DKV_SLOT = 2 * TILE_BYTES + 512;     // Q tile | dO tile | lse[64] | delta[64]
-constexpr int DKV_DMA = 2 * TILE_DMA * DMA_REP + 2;          // DMA wave-instructions per wave per tile 
+constexpr int DKV_DMA = 2 * TILE_DMA + 2;          // DMA wave-instructions per wave per tile 
 constexpr int DKV_WAVES = 2;   // waves per SIMD the register budget is sized for (222 VGPRs; at 3 the kernel spills 118)
 
 template <bool FUSE>
