@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void lerp_fwd_kernel(LerpFwdArgs a) {
   const float skip = a.skip_x ? a.skip[0] : 0.f;
   for (int m = blockIdx.x * ROW_WAVES + wid; m < a.M; m += gridDim.x * ROW_WAVES) {
     RowVec<NV> x, y, r, xs;
-    row_load<NV, float>(x, a.h + (size_t)m * a.C, a.C, lane);
+    row_load_f32_nt<NV>(x, a.h + (size_t)m * a.C, a.C, lane);   // (the residual stream is read once here: streaming load)
     row_load<NV, TY>(y, reinterpret_cast<const TY*>(a.y) + (size_t)m * a.C, a.C, lane);
-    if (a.skip_x) row_load<NV, float>(xs, a.skip_x + (size_t)m * a.C, a.C, lane);   // with the others: one round trip per row
+    if (a.skip_x) row_load_f32_nt<NV>(xs, a.skip_x + (size_t)m * a.C, a.C, lane);   // with the others: one round trip per row
     const float rsx = 1.0f / sqrtf(row_dot<NV>(x, x));
     const float rsy = 1.0f / sqrtf(row_dot<NV>(y, y));
 #pragma unroll
