@@ -107,7 +107,11 @@ __global__ __launch_bounds__(256) void lerp_fwd_kernel(LerpFwdArgs a) {
 #pragma unroll
       for (int i = 0; i < NV; ++i) r.v[i] = r.v[i] * rst;
     }
-    row_store<NV, float>(r, a.out + (size_t)m * a.C, a.C, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {   // the fp32 stream is read again only far later (next block / backward): streaming store
+      const int c = (i * 64 + lane) * 4;
+      if (c < a.C) __builtin_nontemporal_store(r.v[i], reinterpret_cast<f32x4*>(a.out + (size_t)m * a.C + c));
+    }
     if (a.out_lo) row_store<NV, TL>(r, reinterpret_cast<TL*>(a.out_lo) + (size_t)m * a.C, a.C, lane);
   }
 }
