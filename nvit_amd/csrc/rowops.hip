@@ -88,7 +88,21 @@ __global__ __launch_bounds__(256) void lerp_fwd_kernel(LerpFwdArgs a) {
   for (int m = blockIdx.x * ROW_WAVES + wid; m < a.M; m += gridDim.x * ROW_WAVES) {
     RowVec<NV> x, y, r, xs;
     row_load_f32_nt<NV>(x, a.h + (size_t)m * a.C, a.C, lane);   // (the residual stream is read once here: streaming load)
-    row_load<NV, TY>(y, reinterpret_cast<const TY*>(a.y) + (size_t)m * a.C, a.C, lane);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (i * 64 + lane) * 4;
+      if constexpr (sizeof(TY) == 2) {
+        uint2 raw = make_uint2(0u, 0u);
+        if (c < a.C) {
+          typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+          raw = __builtin_bit_cast(uint2, __builtin_nontemporal_load(reinterpret_cast<const u32x2_*>(reinterpret_cast<const TY*>(a.y) + (size_t)m * a.C + c)));
+        }
+        const bf16x4 b4 = __builtin_bit_cast(bf16x4, raw);
+        y.v[i] = (f32x4){(float)b4[0], (float)b4[1], (float)b4[2], (float)b4[3]};
+      } else {
+        y.v[i] = c < a.C ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(a.y) + (size_t)m * a.C + c)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
     if (a.skip_x) row_load_f32_nt<NV>(xs, a.skip_x + (size_t)m * a.C, a.C, lane);   // with the others: one round trip per row
     const float rsx = 1.0f / sqrtf(row_dot<NV>(x, x));
     const float rsy = 1.0f / sqrtf(row_dot<NV>(y, y));
