@@ -37,13 +37,8 @@ struct TnpArgs {
 
 __device__ __forceinline__ int tnp_swz(int m) { return (((m & 3) | (((m >> 3) & 1) << 2)) << 1); }
 
-#ifdef NVIT_TN_NUM_VGPR   // experiments (tools/overlap_probe.py): cap the register allocation so that a row kernel fits beside two waves
-#define NVIT_TN_VGPR_ATTR __attribute__((amdgpu_num_vgpr(NVIT_TN_NUM_VGPR)))
-#else
-#define NVIT_TN_VGPR_ATTR
-#endif
 template <typename T, int DEEP>
-__global__ __launch_bounds__(512) NVIT_TN_VGPR_ATTR void gemm_tn_persistent_kernel(TnpArgs g) {
+__global__ __launch_bounds__(512) void gemm_tn_persistent_kernel(TnpArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NSLOT = DEEP ? 4 : 2;
   constexpr int TSLOT_BYTES = TN_LDS / NSLOT;        // 64 / 32 KiB

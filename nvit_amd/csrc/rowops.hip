@@ -39,27 +39,16 @@ __device__ __forceinline__ float row_dot(const RowVec<NV>& a, const RowVec<NV>& 
   return wave_sum(s);
 }
 
-// Streaming variants (read-once inputs / write-once outputs of the backward row kernel): non-temporal accesses, switched
-// by NVIT_LERP_BWD_NT (experiments: 1 = loads, 2 = stores, 3 = both).
-#ifndef NVIT_LERP_BWD_NT
-#define NVIT_LERP_BWD_NT 1   // measured: loads -0.34 ms per Base step, stores +-0 (tools/ab_lib.sh)
-#endif
+// Streaming (non-temporal) loads of read-once fp32 rows: the residual stream and the incoming gradient are not read again
+// soon, keeping them out of the caches leaves room for what the neighbouring GEMMs re-read (measured on the whole step:
+// backward -0.34 ms in round 3, forward -0.35 ms in round 4; streaming STORES of the backward outputs: +-0, not used).
 template <int NV>
 __device__ __forceinline__ void row_load_f32_nt(RowVec<NV>& r, const float* p, int C, int lane) {
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = (i * 64 + lane) * 4;
-    if constexpr ((NVIT_LERP_BWD_NT & 1) != 0)
-      r.v[i] = c < C ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    else
-      r.v[i] = c < C ? load4<float>(p + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    r.v[i] = c < C ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + c)) : (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-}
-__device__ __forceinline__ void store4_f32_nt(float* p, f32x4 v) {
-  if constexpr ((NVIT_LERP_BWD_NT & 2) != 0)
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
-  else
-    store4<float>(p, v);
 }
 
 // ------------------------------------------------------------------------------ LERP forward
@@ -165,13 +154,10 @@ __device__ __forceinline__ float dot4(const f32x4& a, const f32x4& b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
 }
 
-#ifndef NVIT_LERP_BWD_WAVES
-#define NVIT_LERP_BWD_WAVES 1
-#endif
 // SKIP (norm_skip fused behind the LERP: the MLP half of a block) and ACCUM (dh += : the attention half, whose dh already
 // holds the gradient of the skip path) are template switches as well: a row then keeps 5 vectors in flight instead of 6.
 template <int NV, typename TY, typename TL, bool ADD, bool SKIP, bool ACCUM>
-__global__ __launch_bounds__(256, (NV <= 3 ? NVIT_LERP_BWD_WAVES : 1)) void lerp_bwd_kernel(LerpBwdArgs a) {
+__global__ __launch_bounds__(256, 1) void lerp_bwd_kernel(LerpBwdArgs a) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   RowVec<NV> lam, dlam;
   row_load<NV, float>(lam, a.alpha, a.C, lane);
@@ -272,7 +258,7 @@ __global__ __launch_bounds__(256, (NV <= 3 ? NVIT_LERP_BWD_WAVES : 1)) void lerp
       const f32x4 dy = (db - bv.v[i] * bdb) * rsy;
       if constexpr (ACCUM) dh += old.v[i];
       if (c < a.C) {
-        store4_f32_nt(a.dh + ro + c, dh);
+        store4<float>(a.dh + ro + c, dh);
         if (a.dy) store4<float>(a.dy + ro + c, dy);
         if (a.dy_lo) store4<TL>(reinterpret_cast<TL*>(a.dy_lo) + ro + c, dy);
       }

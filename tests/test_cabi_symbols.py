@@ -81,6 +81,11 @@ def test_product_sources_carry_no_probe_switches():
     for f in files:
         hits = [ln for ln in open(f) if re.search(r"#\s*if.*NVIT_PROBE", ln)]
         assert not hits, (f, hits[:3])
+        # ... and no other compile-time experiment switch either: the only NVIT_* macros a conditional may test are the
+        # product-build guard and include guards (run-time switches go through nvit_set_* / environment variables)
+        cond = [ln for ln in open(f) if re.match(r"\s*#\s*(if|ifdef|ifndef|elif)\b.*\bNVIT_", ln)
+                and not re.search(r"NVIT_PRODUCT_BUILD|NVIT_[A-Z_]*_H_?\b", ln)]
+        assert not cond, (f, cond[:3])
     mk = open(os.path.join(csrc, "Makefile")).read()
     listed = set(re.search(r"^SRCS\s*=\s*(.*)$", mk, re.M).group(1).split())
     assert listed == {os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.hip"))}
